@@ -1,0 +1,422 @@
+#!/usr/bin/env python3
+"""Generate tests/golden/*.npz from the REFERENCE itself and pin the oracle against it.
+
+Run in the build container only (needs /root/reference; nothing here runs on the GPU box):
+
+    python tests/golden/make_golden.py            # all pins + fixtures
+    python tests/golden/make_golden.py --skip-script   # skip the end-to-end script run (slow part)
+
+What it does
+  1. imports /root/reference/src/model.py unmodified (a 2-line in-memory stub stands in for the absent
+     ``torchsummaryX`` package, whose ``summary`` is only used under ``__main__``),
+  2. PIN A: seeded construction of the reference Generator/Discriminator/DF == oracle.make_*_state (bit-exact),
+  3. PIN B: replays the loop body src/mlp_df_wgan_train.py:184-275 around the reference's own nn.Modules
+     (their nn.Dropout draws from the global generator), recovers the dropout masks by RNG replay, and asserts
+     oracle.iteration(...) with those masks injected reproduces every scalar / tensor bit-for-bit,
+  4. PIN C: runs the unmodified trainer script end-to-end (runpy, seeded) on a tiny dataset and compares its
+     artefacts with oracle.train_loop.run_training under the same seeds,
+  5. PIN D: reference-style sampling (generate.py:48-64 call sequence around the reference Generator and a real
+     sklearn MinMaxScaler) == oracle.sample,
+  6. writes the fixtures (inputs, masks as packed bits, expected outputs).  Weights are NOT stored: tests
+     re-derive them from the seed with oracle.make_state and check the stored checksums.
+"""
+import argparse
+import json
+import os
+import runpy
+import sys
+import tempfile
+import types
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, ROOT)
+REF_SRC = "/root/reference/src"
+
+from oracle import wfdgan_oracle as O          # noqa: E402
+from oracle import train_loop as TL            # noqa: E402
+
+
+def import_reference_model():
+    stub = types.ModuleType("torchsummaryX")
+    stub.summary = lambda *a, **k: None
+    sys.modules.setdefault("torchsummaryX", stub)
+    stub2 = types.ModuleType("torchsummary")
+    stub2.summary = lambda *a, **k: None
+    sys.modules.setdefault("torchsummary", stub2)
+    if REF_SRC not in sys.path:
+        sys.path.insert(0, REF_SRC)
+    import model as ref_model                  # noqa
+    return ref_model
+
+
+def checksum(sd):
+    return float(sum(float(v.detach().double().abs().sum()) for v in sd.values() if v.is_floating_point()))
+
+
+def assert_same(a, b, what):
+    a = torch.as_tensor(a)
+    b = torch.as_tensor(b)
+    if not torch.equal(a, b):
+        diff = (a.double() - b.double()).abs().max()
+        raise AssertionError(f"{what}: differs, max abs diff {diff}")
+
+
+# ------------------------------------------------------------------------------------------------
+def ref_build(ref_model, seq_len, class_dim, latent_dim, smin, smax, seed, df_sd):
+    torch.manual_seed(seed)
+    G = ref_model.Generator(seq_len, class_dim, latent_dim, scaler_min=smin, scaler_max=smax, is_gpu=False)
+    D = ref_model.Discriminator(seq_len, class_dim)
+    DFm = ref_model.DF(seq_len - 1, class_dim)
+    if df_sd is not None:
+        DFm.load_state_dict(df_sd)
+    DFm.eval()
+    return G, D, DFm
+
+
+def ref_iteration(G, D, DFm, optG, optD, traces, c, z, do_g, alpha, class_dim):
+    """Loop body of src/mlp_df_wgan_train.py:184-275 around the reference modules (W-div, as it runs)."""
+    import torch.autograd as autograd
+    out = {}
+    real = traces.float().requires_grad_(True)
+    c_onehot = torch.Tensor(np.eye(class_dim)[c.numpy()])
+    c = c.long()
+    optD.zero_grad()
+    fake = G(z, c_onehot)
+    rv = D(real, c_onehot)
+    fv = D(fake, c_onehot)
+    ones = torch.ones(real.size(0), 1)
+    g_r = autograd.grad(rv, real, ones, create_graph=True, retain_graph=True, only_inputs=True)[0]
+    n_r = g_r.view(g_r.size(0), -1).pow(2).sum(1) ** (O.P_DIV / 2)
+    g_f = autograd.grad(fv, fake, ones, create_graph=True, retain_graph=True, only_inputs=True)[0]
+    n_f = g_f.view(g_f.size(0), -1).pow(2).sum(1) ** (O.P_DIV / 2)
+    div_gp = torch.mean(n_r + n_f) * O.K_DIV / 2
+    d_loss = -torch.mean(rv) + torch.mean(fv) + div_gp
+    out.update(n_r=n_r.detach().clone(), n_f=n_f.detach().clone(), penalty=float(div_gp),
+               mean_rv=float(torch.mean(rv)), mean_fv=float(torch.mean(fv)),
+               w_dist=float(torch.mean(rv) - torch.mean(fv)), d_loss=float(d_loss),
+               fake_d=fake.detach().clone(), rv=rv.detach().clone(), fv=fv.detach().clone())
+    d_loss.backward()
+    out["d_grads"] = [p.grad.detach().clone() for p in D.parameters()]
+    optD.step()
+    optG.zero_grad()
+    if do_g:
+        fake = G(z, c_onehot)
+        fv = D(fake, c_onehot)
+        g_loss = -torch.mean(fv)
+        sel = fv[:, 0] > 0
+        if int(sel.sum()) > 0:
+            conv = fake[sel][:, 1:]
+            conv = conv.reshape(conv.size(0), 1, conv.size(1))
+            f_loss = torch.nn.CrossEntropyLoss()(DFm(conv), c[sel])
+            comb = g_loss + alpha * f_loss
+            f_item = float(f_loss)
+        else:
+            comb = g_loss
+            f_item = 0.0
+        out.update(g_loss=float(g_loss), f_loss=f_item, g_combined=float(comb), n_sel=int(sel.sum()),
+                   fake_g=fake.detach().clone(), fv_g=fv.detach().clone())
+        comb.backward()
+        out["g_grads"] = [p.grad.detach().clone() for p in G.parameters()]
+        optG.step()
+    return out
+
+
+def pack_masks(masks):
+    return [np.packbits((m.numpy() != 0).astype(np.uint8), axis=None) for m in masks]
+
+
+def slices(t, n=16):
+    f = t.detach().flatten()
+    step = max(1, f.numel() // n)
+    return f[::step][:n].clone().numpy()
+
+
+def make_case(ref_model, name, seq_len, class_dim, latent_dim, batch, n_iter, seed, data_seed, lr=2e-4,
+              alpha=0.02, n_critic=3, full_rows=4):
+    """One fixture: n_iter iterations from seeded init, on seeded synthetic data."""
+    print(f"[case {name}] S={seq_len} C={class_dim} Z={latent_dim} B={batch} iters={n_iter}")
+    L = seq_len - 1
+    X, y = O.synth_dataset(class_dim, max(2, (batch * n_iter) // class_dim + 1), L, max(2, L // 20),
+                           75 if L > 600 else 13, 179 if L > 600 else 122, seed=data_seed)
+    dmin, dmax = X.min(0), X.max(0)
+    scale, min_ = O.scaler_params(dmin, dmax)
+    Xs = X * scale + min_
+    smin, smax = dmin[0], dmax[0]
+    rng = np.random.default_rng(data_seed + 1)
+    perm = rng.permutation(X.shape[0])
+
+    # frozen observer: seeded init + perturbed BN statistics
+    torch.manual_seed(seed + 100)
+    df_sd = O.make_df_state(L, class_dim)
+    O.perturb_df_bn(df_sd, seed + 101)
+
+    G, D, DFm = ref_build(ref_model, seq_len, class_dim, latent_dim, smin, smax, seed, df_sd)
+    optG = torch.optim.RMSprop(G.parameters(), lr=lr)
+    optD = torch.optim.RMSprop(D.parameters(), lr=lr)
+    st = O.make_state(seq_len, class_dim, latent_dim, smin, smax, seed, df_state=df_sd, lr=lr, alpha=alpha,
+                      n_critic=n_critic)
+    # PIN A
+    for k, v in G.state_dict().items():
+        assert_same(v, st.G[k], f"G init {k}")
+    for k, v in D.state_dict().items():
+        assert_same(v, st.D[k], f"D init {k}")
+    for k, v in DFm.state_dict().items():
+        assert_same(v, st.DF[k], f"DF init {k}")
+
+    fx = dict(meta=json.dumps(dict(name=name, seq_len=seq_len, class_dim=class_dim, latent_dim=latent_dim,
+                                   batch=batch, n_iter=n_iter, seed=seed, df_seed=seed + 100,
+                                   df_bn_seed=seed + 101, lr=lr, alpha=alpha, n_critic=n_critic,
+                                   scaler_min=float(smin), scaler_max=float(smax),
+                                   torch=torch.__version__)),
+              g_init_checksum=checksum(st.G), d_init_checksum=checksum(st.D), df_checksum=checksum(st.DF))
+    zrng = np.random.RandomState(seed + 7)
+    torch.manual_seed(seed + 13)                     # dropout stream for the run
+    for it in range(n_iter):
+        idx = perm[it * batch:(it + 1) * batch]
+        traces = torch.from_numpy(Xs[idx])           # float64, as the DataLoader hands it over
+        c = torch.from_numpy(y[idx])
+        z64 = zrng.normal(0, 1, (batch, latent_dim))
+        z = torch.Tensor(z64)
+        do_g = (it % n_critic == 0)
+        rng_state = torch.get_rng_state()
+        r_ref = ref_iteration(G, D, DFm, optG, optD, traces, c, z, do_g, alpha, class_dim)
+        after = torch.get_rng_state()
+        # recover the masks the reference's nn.Dropout layers drew
+        torch.set_rng_state(rng_state)
+        m_real = O.draw_dropout_masks(batch)
+        m_fake = O.draw_dropout_masks(batch)
+        m_g = O.draw_dropout_masks(batch) if do_g else None
+        assert torch.equal(torch.get_rng_state(), after), "dropout replay consumed a different RNG stream"
+        r = O.iteration(st, traces, c, z, do_g, m_real, m_fake, m_g, keep=True)
+        # PIN B: oracle == reference modules, bit for bit
+        for k in ("d_loss", "penalty", "w_dist", "mean_rv", "mean_fv"):
+            assert r[k] == r_ref[k], (k, r[k], r_ref[k])
+        for k in ("n_r", "n_f", "fake_d", "rv", "fv"):
+            assert_same(r[k], r_ref[k], f"it{it} {k}")
+        for a, b in zip(r["d_grads"], r_ref["d_grads"]):
+            assert_same(a, b, f"it{it} d_grads")
+        if do_g:
+            for k in ("g_loss", "f_loss", "g_combined", "n_sel"):
+                assert r[k] == r_ref[k], (k, r[k], r_ref[k])
+            assert_same(r["fake_g"], r_ref["fake_g"], f"it{it} fake_g")
+            for a, b in zip(r["g_grads"], r_ref["g_grads"]):
+                assert_same(a, b, f"it{it} g_grads")
+        for k, v in G.state_dict().items():
+            assert_same(v, st.G[k].detach(), f"it{it} G param {k}")
+        for k, v in D.state_dict().items():
+            assert_same(v, st.D[k].detach(), f"it{it} D param {k}")
+        print(f"   it{it}: d_loss={r['d_loss']:.6f} pen={r['penalty']:.6e} w={r['w_dist']:.6f}"
+              + (f" g={r['g_loss']:.6f} f={r['f_loss']:.6f} nsel={r['n_sel']}" if do_g else ""))
+
+        p = f"it{it}_"
+        fx[p + "traces"] = Xs[idx].astype(np.float32)
+        fx[p + "labels"] = y[idx]
+        fx[p + "z"] = z.numpy()
+        for nm, ms in (("mreal", m_real), ("mfake", m_fake), ("mg", m_g)):
+            if ms is not None:
+                for li, pk in enumerate(pack_masks(ms)):
+                    fx[f"{p}{nm}{li}"] = pk
+        fx[p + "scalars"] = np.array([r_ref["d_loss"], r_ref["penalty"], r_ref["w_dist"], r_ref["mean_rv"],
+                                      r_ref["mean_fv"]], dtype=np.float64)
+        fx[p + "n_r"], fx[p + "n_f"] = r_ref["n_r"].numpy(), r_ref["n_f"].numpy()
+        fx[p + "idx_d"] = r["idx_d"].numpy()
+        fx[p + "rv"], fx[p + "fv"] = r_ref["rv"].numpy(), r_ref["fv"].numpy()
+        fx[p + "fake_d_rowsum"] = r_ref["fake_d"].double().sum(1).numpy()
+        fx[p + "fake_d_rows"] = r_ref["fake_d"][:full_rows].numpy()
+        fx[p + "d_grad_norms"] = np.array([float(g.double().norm()) for g in r_ref["d_grads"]])
+        fx[p + "d_grad_slices"] = np.stack([slices(g) if g.numel() >= 16 else np.resize(g.numpy().flatten(), 16)
+                                            for g in r_ref["d_grads"]])
+        fx[p + "d_param_slices"] = np.stack([slices(q) if q.numel() >= 16 else np.resize(q.detach().numpy().flatten(), 16)
+                                             for q in D.parameters()])
+        fx[p + "d_param_norms"] = np.array([float(q.detach().double().norm()) for q in D.parameters()])
+        if do_g:
+            fx[p + "g_scalars"] = np.array([r_ref["g_loss"], r_ref["f_loss"], r_ref["g_combined"],
+                                            r_ref["n_sel"]], dtype=np.float64)
+            fx[p + "idx_g"] = r["idx_g"].numpy()
+            fx[p + "fv_g"] = r_ref["fv_g"].numpy()
+            fx[p + "fake_g_rowsum"] = r_ref["fake_g"].double().sum(1).numpy()
+            fx[p + "fake_g_rows"] = r_ref["fake_g"][:full_rows].numpy()
+            fx[p + "g_grad_norms"] = np.array([float(g.double().norm()) for g in r_ref["g_grads"]])
+            fx[p + "g_grad_slices"] = np.stack([slices(g) for g in r_ref["g_grads"]])
+        fx[p + "g_param_slices"] = np.stack([slices(q) for q in G.parameters()])
+        fx[p + "g_param_norms"] = np.array([float(q.detach().double().norm()) for q in G.parameters()])
+        gsd = G.state_dict()
+        fx[p + "g_bn_stats"] = np.concatenate([gsd[f"model.{i}.{s}"].numpy() for i in (3, 6)
+                                               for s in ("running_mean", "running_var")])
+    np.savez_compressed(os.path.join(HERE, f"iter_{name}.npz"), **fx)
+    print(f"   wrote iter_{name}.npz")
+
+
+# ------------------------------------------------------------------------------------------------
+def make_sampler_case(ref_model, name, seq_len, class_dim, latent_dim, n_cases, seed):
+    """PIN D + fixture: reference-style sample() vs oracle.sample, including adversarial rows."""
+    from sklearn import preprocessing
+    print(f"[sampler {name}]")
+    L = seq_len - 1
+    X, y = O.synth_dataset(class_dim, 8, L, max(2, L // 20), 75, 179, seed=seed)
+    X[:, 5] = 7.0                                   # a constant column: scale_ = 1 path
+    scaler = preprocessing.MinMaxScaler()
+    scaler.fit(X)
+    scale, min_ = O.scaler_params(scaler.data_min_, scaler.data_max_)
+    assert np.array_equal(scale, scaler.scale_) and np.array_equal(min_, scaler.min_)
+    torch.manual_seed(seed)
+    G = ref_model.Generator(seq_len, class_dim, latent_dim, scaler_min=scaler.data_min_[0],
+                            scaler_max=scaler.data_max_[0], is_gpu=False)
+    # non-trivial running statistics, as after training
+    g = torch.Generator().manual_seed(seed + 1)
+    sd = G.state_dict()
+    for k in sd:
+        if k.endswith("running_mean"):
+            sd[k] = torch.randn(sd[k].shape, generator=g) * 0.05
+        elif k.endswith("running_var"):
+            sd[k] = torch.rand(sd[k].shape, generator=g) * 0.2 + 0.05
+    G.load_state_dict(sd)
+    G.eval()
+    osd = {k: v.clone() for k, v in G.state_dict().items()}
+    zr = np.random.RandomState(seed + 2)
+    Z = zr.randn(n_cases, latent_dim).astype("float32")
+    C = zr.randint(0, class_dim, n_cases)
+    outs, lens, ys = [], [], []
+    for i in range(n_cases):
+        with torch.no_grad():
+            zt = torch.from_numpy(Z[i:i + 1])
+            c = torch.zeros(1, class_dim)
+            c[:, C[i]] = 1
+            sx = G(zt, c).cpu().numpy()
+            ys.append(sx[0].copy())
+            sx = sx.mean(axis=0).reshape(1, -1)
+            sx = scaler.inverse_transform(sx).flatten()
+            sx = np.round(np.trim_zeros(sx)).astype(int)
+            sx[sx == 0] = 1
+        mine = O.sample(osd, int(C[i]), Z[i:i + 1], class_dim, scaler.data_min_[0], scaler.data_max_[0], scale, min_)
+        assert np.array_equal(sx, mine), f"sampler case {i}"
+        outs.append(sx)
+        lens.append(len(sx))
+    # adversarial post-processing rows: values whose inverse-transform lands on .5 exactly, zeros inside the
+    # row, leading zeros (trim_zeros trims both ends), all-zero row
+    adv = []
+    r = np.random.RandomState(seed + 3)
+    for i in range(32):
+        row = np.zeros(seq_len, dtype=np.float32)
+        n = int(r.randint(3, seq_len - 1))
+        tgt = r.randint(0, 40, n).astype(np.float64) + 0.5 * (r.rand(n) < 0.5)
+        row[:n] = ((tgt * scale[:n]) + min_[:n]).astype(np.float32)
+        if i % 4 == 1:
+            row[0] = 0.0
+        if i % 4 == 2:
+            row[n // 2] = 0.0
+        if i == 31:
+            row[:] = 0.0
+        adv.append(row)
+    adv = np.stack(adv)
+    adv_out = []
+    for row in adv:
+        sx = scaler.inverse_transform(row.reshape(1, -1).copy()).flatten()
+        sx = np.round(np.trim_zeros(sx)).astype(int)
+        sx[sx == 0] = 1
+        mine = O.sample_postprocess(row, scale, min_)
+        assert np.array_equal(sx, mine)
+        adv_out.append(sx)
+    maxlen = seq_len
+    pad = lambda rows: np.stack([np.pad(o, (0, maxlen - len(o))) for o in rows]).astype(np.int64)
+    np.savez_compressed(os.path.join(HERE, f"sampler_{name}.npz"),
+                        meta=json.dumps(dict(seq_len=seq_len, class_dim=class_dim, latent_dim=latent_dim,
+                                             seed=seed, n_cases=n_cases)),
+                        data_min=scaler.data_min_, data_max=scaler.data_max_, z=Z, c=C,
+                        y=np.stack(ys), out=pad(outs), out_len=np.array(lens),
+                        adv_in=adv, adv_out=pad(adv_out), adv_len=np.array([len(o) for o in adv_out]),
+                        g_checksum=checksum(osd),
+                        bn_seed=seed + 1)
+    print(f"   wrote sampler_{name}.npz ({n_cases} sampled + {len(adv)} adversarial rows)")
+
+
+# ------------------------------------------------------------------------------------------------
+def pin_script_end_to_end():
+    """PIN C: unmodified reference trainer (runpy) vs oracle.train_loop.run_training, same seeds."""
+    print("[script] running the unmodified reference trainer end-to-end (tiny config-1-like dataset)")
+    n_cls, n_inst, L = 10, 20, 500
+    X, y = O.synth_dataset(n_cls, n_inst, L, 20, 13, 122, seed=0)
+    torch.manual_seed(0)
+    df_sd = O.make_df_state(L, n_cls)
+    tmp = tempfile.mkdtemp(prefix="wfdgan_ref_")
+    ddir = os.path.join(tmp, "a", "b")
+    os.makedirs(ddir)
+    npz = os.path.join(ddir, "raw_feature_synth.npz")
+    np.savez(npz, features=X, labels=y)
+    ckpt = os.path.join(tmp, "df.ckpt")
+    torch.save(df_sd, ckpt)
+    import_reference_model()
+    argv = sys.argv
+    sys.argv = ["mlp_df_wgan_train.py", "-d", npz, "--f_model", ckpt, "--n_epochs", "2", "--n_cpu", "0",
+                "--latent_dim", "64"]
+    cwd = os.getcwd()
+    os.chdir(REF_SRC)
+    torch.manual_seed(1234)
+    np.random.seed(4321)
+    try:
+        runpy.run_path(os.path.join(REF_SRC, "mlp_df_wgan_train.py"), run_name="__main__")
+    finally:
+        sys.argv = argv
+        os.chdir(cwd)
+    # utils.init_directory writes to the grandparent of --dir (src/utils.py:44-52)
+    par = os.path.join(tmp, "a")
+    outdir = [d for d in os.listdir(par) if d.startswith("training_")][0]
+    base = os.path.join(par, outdir)
+    ref_loss = np.load(os.path.join(base, "checkpoint", "loss.npz"))
+    ref_ep1 = np.load(os.path.join(base, "checkpoint", "epoch_1.npz"))
+    ref_G = torch.load(os.path.join(base, "model", "generator_seqlen501_cls10_latentdim64.ckpt"), weights_only=True)
+    ref_D = torch.load(os.path.join(base, "model", "discriminator.ckpt"), weights_only=True)
+
+    torch.manual_seed(1234)
+    np.random.seed(4321)
+    mine = TL.run_training(X.copy(), y.copy(), df_sd, n_epochs=2, n_cpu=0, latent_dim=64)
+    for k in ("generator", "discriminator", "dist"):
+        a, b = np.asarray(ref_loss[k]), np.asarray(mine["losses"][k])
+        assert np.array_equal(a, b), (k, a, b)
+    assert np.array_equal(ref_ep1["recon_x"], mine["dumps"][1]["recon_x"])
+    assert np.array_equal(ref_ep1["x"], mine["dumps"][1]["x"])
+    assert np.array_equal(ref_ep1["label"], mine["dumps"][1]["label"])
+    for k, v in ref_G.items():
+        assert_same(v, mine["G"][k], f"script G {k}")
+    for k, v in ref_D.items():
+        assert_same(v, mine["D"][k], f"script D {k}")
+    print("   script artefacts == oracle run_training (loss.npz, epoch_1.npz, generator/discriminator ckpt): bit-exact")
+    np.savez_compressed(os.path.join(HERE, "script_run.npz"),
+                        meta=json.dumps(dict(n_cls=n_cls, n_inst=n_inst, L=L, torch_seed=1234, np_seed=4321,
+                                             n_epochs=2, latent_dim=64, df_seed=0)),
+                        **{f"loss_{k}": np.asarray(ref_loss[k]) for k in ("generator", "discriminator", "dist")},
+                        recon_x_rowsum=ref_ep1["recon_x"].astype(np.float64).sum(1),
+                        label=ref_ep1["label"],
+                        g_checksum=checksum(ref_G), d_checksum=checksum(ref_D))
+    print("   wrote script_run.npz")
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--skip-script", action="store_true")
+    ap.add_argument("--only", default="")
+    args = ap.parse_args()
+    torch.set_num_threads(8)
+    ref_model = import_reference_model()
+    if not args.only or args.only == "tiny":
+        make_case(ref_model, "tiny", seq_len=41, class_dim=5, latent_dim=16, batch=8, n_iter=4, seed=3, data_seed=5)
+    if not args.only or args.only == "cfg1":
+        make_case(ref_model, "cfg1", seq_len=501, class_dim=10, latent_dim=500, batch=64, n_iter=4, seed=11,
+                  data_seed=0)
+    if not args.only or args.only == "cfg2":
+        make_case(ref_model, "cfg2", seq_len=1401, class_dim=100, latent_dim=500, batch=64, n_iter=2, seed=21,
+                  data_seed=0)
+    if not args.only or args.only == "sampler":
+        make_sampler_case(ref_model, "cfg2", 1401, 100, 500, 100, seed=31)
+        make_sampler_case(ref_model, "tiny", 41, 5, 16, 50, seed=32)
+    if not args.skip_script and (not args.only or args.only == "script"):
+        pin_script_end_to_end()
+    print("ALL PINS PASSED")
+
+
+if __name__ == "__main__":
+    main()
