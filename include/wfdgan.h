@@ -1,0 +1,170 @@
+/* wfdgan.h -- C ABI of libwfdgan_hip.so: MI355X (gfx950) kernels for the wfd-gan training / sampling hot path.
+ *
+ * The reference (websitefingerprinting/wfd-gan) is pure Python: it has no FFI of its own, its "operator
+ * interface" for this path is the ATen ops that src/model.py and src/mlp_df_wgan_train.py dispatch.  Each entry
+ * point below replaces the cited op sequence.  Citations are file:line under the reference's root.
+ *
+ * Conventions
+ *   - plain pointers + sizes; every pointer is DEVICE memory owned by the caller; nothing here allocates.
+ *   - `stream` is a hipStream_t (0 = default stream); all calls are asynchronous and graph-capturable.
+ *   - return value: 0 ok, 1 bad argument, 2 launch failure.
+ *   - matrices are row-major fp32 with an explicit leading dimension (floats).
+ *   - "slabs": a GEMM writes `ns` partial products P[z][M][ldp] (z < ns, `ss` floats apart); the epilogue
+ *     entry points take (P, ns, ss, ldp) and sum the slabs in z order while applying their math.
+ *
+ * The Python binding (wfd_gan_amd/_lib.py) parses THIS file to build its ctypes signatures: keep one
+ * declaration per statement, types from {int, long, float, double, unsigned long long, T*}.
+ */
+#ifndef WFDGAN_H
+#define WFDGAN_H
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+int wfd_version(void);
+
+/* ---- dense contractions (fp32 MFMA, exact f32 products) ------------------------------------------------ */
+
+/* Split count the library recommends for an MxNxK product (fills 256 CUs when the batch dimension is tiny). */
+int wfd_gemm_pick_splits(int M, int N, int K);
+
+/* layout 0 (NT): P = A[M][K] * B[N][K]^T   -- nn.Linear forward (torch addmm), src/model.py:28-32,57-66,187-196
+ * layout 1 (NN): P = A[M][K] * B[K][N]     -- input-gradient of nn.Linear: autograd.grad / backward,
+ *                                             src/mlp_df_wgan_train.py:204-206,210-212,229,273
+ * layout 2 (TN): P = A[K][M]^T * B[K][N]   -- weight-gradient of nn.Linear (reduction over batch rows), :229,:273 */
+int wfd_gemm_f32(int layout, const float* A, int lda, const float* B, int ldb, float* P, int ldp, long slab_stride,
+                 int M, int N, int K, int splits, void* stream);
+
+/* k=8 stride-1 "SAME" Conv1d over a channels-last activation X[B][L][Cin] as an implicit GEMM,
+ * P[b*L+l][co] = sum_{t,ci} X[b][l+t-pad][ci] * Wp[co][t*Cin+ci]; pad 3 = forward (src/model.py:92-105, F.pad
+ * left 3 / right 4 + nn.Conv1d), pad 4 with tap-flipped transposed weights = its input gradient (:273). */
+int wfd_conv8_gemm_f32(const float* X, int Bn, int L, int Cin, int pad, const float* Wp, int Cout, float* P, int ldp,
+                       long slab_stride, int splits, void* stream);
+
+/* ---- MLP epilogues ------------------------------------------------------------------------------------ */
+
+/* out = act(sumP * scale[n] + shift[n]); act 0 none, 1 ReLU, 2 ELU, 3 sigmoid; scale/shift may be NULL.
+ * bias + nn.ReLU (src/model.py:21,24), eval-mode BatchNorm folded to scale/shift + ELU/ReLU (:143-183,188-193). */
+int wfd_ep_affine_act(const float* P, int ns, long ss, int ldp, int M, int N, const float* scale, const float* shift,
+                      int act, float* out, int ldo, void* stream);
+
+/* Discriminator hidden layer: z = sumP + bias; H = LeakyReLU(z, slope) * mask; D = mask * (z > 0 ? 1 : slope).
+ * nn.LeakyReLU(0.2) + nn.Dropout(0.2), src/model.py:58-65; mask holds {0, 1/(1-p)} (explicit for parity, from
+ * wfd_rng_dropout_mask otherwise).  D is the layer's local derivative, kept for the input-gradient chain. */
+int wfd_ep_lrelu_drop(const float* P, int ns, long ss, int ldp, int M, int N, const float* bias, const float* mask,
+                      int ldmask, float slope, float* H, int ldh, float* D, int ldd, void* stream);
+
+/* Discriminator head nn.Linear(512,1) (src/model.py:66) as a wave-reduced GEMV, fused with the first step of
+ * d validity / d input:  v = <H3,w4> + b4;  delta = w4 o D3;  delta_s = rowscale[m] * delta (may be NULL). */
+int wfd_d_head(const float* H3, int ldh, const float* D3, int ldd, const float* w4, const float* b4, int M, int K,
+               const float* rowscale, float* v, float* delta, float* delta_s, int ldo, void* stream);
+
+/* out = sumP * f(D) * colscale[n]; dmode 0 none, 1 D, 2 [D > 0] (ReLU'), 3 ELU' from its output; optional
+ * out2 = out * rowscale[m].  One step of autograd.grad(validity, traces, create_graph=True) in closed form
+ * (src/mlp_df_wgan_train.py:204-206) and of backward() through ReLU/ELU + folded BN (:273). */
+int wfd_ep_mul(const float* P, int ns, long ss, int ldp, int M, int N, const float* D, int ldd, int dmode,
+               const float* colscale, const float* rowscale, float* out, float* out2, int ldo, void* stream);
+
+/* Row-wise gradient penalty on g = sumP[m][0..S): nsq = ||g||^2;
+ * mode 0 W-div (k=2,p=6): pen = nsq^3 (src/mlp_df_wgan_train.py:207,213); mode 1 WGAN-GP: pen = (||g||-1)^2
+ * (src/utils.py:82-83).  GH = d(mean penalty)/dg, the seed of the double-backward (d_loss.backward(), :229). */
+int wfd_ep_penalty_row(const float* P, int ns, long ss, int ldp, int M, int S, int mode, float invB, float lambda,
+                       float* nsq, float* pen, float* GH, int ldg, void* stream);
+
+/* out[n] (+)= sum_m X[m][n] * rowscale[m]  -- bias gradients (backward(), :229,:273) */
+int wfd_colsum(const float* X, int ldx, int M, int N, const float* rowscale, float* out, int accumulate,
+               void* stream);
+
+/* torch.optim.RMSprop.step with torch defaults (alpha .99, eps 1e-8), src/mlp_df_wgan_train.py:163-164,230,275,
+ * over one flat parameter buffer; g is multiplied by gscale first (1/world_size after an all-reduce). */
+int wfd_rmsprop(float* p, const float* g, float* sq, long n, float lr, float alpha, float eps, float gscale,
+                void* stream);
+
+/* nn.BatchNorm1d(n, eps=0.8) training forward (src/model.py:23), in two halves so that data-parallel ranks can
+ * combine (mean, M2) in between: stats writes Z = sumP + bias and the per-column mean / sum of squared deviations;
+ * apply writes xhat, relu(gamma*xhat+beta), invstd and updates running_mean / running_var (unbiased) nupd times. */
+int wfd_bn_stats(const float* P, int ns, long ss, int ldp, int M, int N, const float* bias, float* Z, int ldz,
+                 float* mean, float* m2, void* stream);
+int wfd_bn_apply_relu(const float* Z, int ldz, int M, int N, const float* mean, const float* m2, float count, float eps,
+                      const float* gamma, const float* beta, float* XH, float* H, int ldo, float* invstd, float* rmean,
+                      float* rvar, float momentum, int nupd, void* stream);
+int wfd_bn_running_update(const float* mean, const float* m2, float count, int N, float* rmean, float* rvar,
+                          float momentum, int nupd, void* stream);
+
+/* Backward of ReLU + BatchNorm1d (training) (:273). phase bit 0: local column sums (sums[0..N) = sum dy,
+ * sums[N..2N) = sum dy*xhat); bit 1: dz, dgamma, dbeta and the preceding Linear's bias gradient. */
+int wfd_bn_bwd(const float* P, int ns, long ss, int ldp, int M, int N, const float* H, const float* XH, int ldh,
+               const float* gamma, const float* invstd, float count, float* sums, float* DZ, int lddz, float* dgamma,
+               float* dbeta, float* dbias, int phase, void* stream);
+
+/* Generator output: nn.Sigmoid + learned-length tail mask, src/model.py:33,42-47 (replaces zeros_like / index
+ * scatter / cumsum / mul).  idx[m] = trunc(y0*range + smin) + 1; *err |= 1 where the reference would raise
+ * IndexError (idx >= S). */
+int wfd_ep_sigmoid_lenmask(const float* P, int ns, long ss, int ldp, int M, int S, const float* bias, float range,
+                           float smin, float* out, int ldo, int* idx, int* err, void* stream);
+
+/* Backward through the mask and the sigmoid into the generator's last pre-activation (:273):
+ * dz = [j < idx] * (dscale * sumP + dDF[j-1]) * y(1-y); dbias = column sums. */
+int wfd_g_out_bwd(const float* P, int ns, long ss, int ldp, int M, int S, float dscale, const float* dDF, int lddf,
+                  const float* fake, int ldf, const int* idx, float* DZ, int lddz, float* dbias, void* stream);
+
+/* d_loss = -mean(rv) + mean(fv) + pen_weight * sum(pen)/B (src/mlp_df_wgan_train.py:215,218,224,226-227).
+ * out[5] = {d_loss, penalty, w_dist, mean_rv, mean_fv}; acc[3] += {d_loss, w_dist, 1} (device epoch sums). */
+int wfd_d_loss(const float* v, const float* pen, int B, int npen, float invB, float pen_weight, float* out, float* acc,
+               void* stream);
+
+/* out[2] = {g_loss = -mean(fv), nsel = #{fv > 0}} (:247,251) */
+int wfd_g_head(const float* fv, int B, float invB, float* out, void* stream);
+
+/* ---- DF observer (src/model.py:135-212), eval mode ---------------------------------------------------- */
+
+/* first conv (Cin = 1) + folded BN + activation; reads x = X[b*ldx + xoff + l] (fake[:,1:], :257-259) */
+int wfd_df_conv1_fwd(const float* X, int ldx, int xoff, int Bn, int L, const float* W, const float* scale,
+                     const float* shift, int act, float* Y, int Cout, void* stream);
+
+/* MyMaxPool1dPadSame(8,1): zero pad (3,4) then MaxPool1d(8) stride 8, src/model.py:119-132; channels-last */
+int wfd_df_pool8_fwd(const float* Y, int Bn, int L, int C, float* PO, void* stream);
+
+/* backward of pool + activation (1 ReLU, 2 ELU) + folded-BN scale in one pass (:273) */
+int wfd_df_pool8_bwd_act(const float* dPO, const float* Y, int Bn, int L, int C, const float* scale, int act,
+                         float* dC, void* stream);
+
+/* nn.CrossEntropyLoss over the rows with fv > 0 (:251-263) in static-shape form; dlogits carries alpha/nsel */
+int wfd_masked_ce(const float* logits, int ldl, int M, int C, const int* labels, const float* fv, const float* nsel,
+                  float alpha, float* ce, float* dlogits, int lddl, void* stream);
+
+/* out[4] = {g_loss, f_loss, g_loss + alpha f_loss, nsel}; acc[4] += {g_loss, f_loss, combined, 1} (:263-271) */
+int wfd_g_loss(const float* ce, int B, const float* head, float alpha, float* out, float* acc, void* stream);
+
+/* input gradient of the first conv: dX[b][l] = sum_{co,t} W[co][t] dC[b][l-t+3][co] (:273) */
+int wfd_df_conv1_bwd(const float* dC, int Bn, int L, int Cout, const float* W, float* dX, int lddx, void* stream);
+
+/* ---- data side ---------------------------------------------------------------------------------------- */
+
+/* nn.Dropout keep-mask values {0, 1/(1-p)} from Philox4x32-10 (fast mode; parity tests pass explicit masks) */
+int wfd_rng_dropout_mask(float* out, long n, float p, unsigned long long seed, unsigned long long offset,
+                         void* stream);
+
+/* z ~ N(0,1) (np.random.normal, src/mlp_df_wgan_train.py:194; np.random.randn, src/generate.py:53) on device */
+int wfd_rng_normal_rows(float* out, int ld, int M, int Z, unsigned long long seed, unsigned long long offset,
+                        void* stream);
+
+/* one training batch: rows idx[] of the resident dataset + one-hot labels into the real / fake / generator-input
+ * buffers (DataLoader + np.eye(class_dim)[c], src/mlp_df_wgan_train.py:182-186) */
+int wfd_gather_batch(const float* X, int ldX, const int* y, const long long* idx, int B, int S, int C, float* real,
+                     float* fake, int ldd, float* zin, int ldz, int Z, int* labels_out, void* stream);
+
+int wfd_onehot_rows(const int* labels, int M, int C, float* out, int ld, int col0, void* stream);
+
+/* --clip: my_clip over every row, src/mlp_df_wgan_train.py:82-91,122 (float64, in place) */
+int wfd_clip_bursts(double* X, long N, int S, double max_len, double max_out, double max_in, void* stream);
+
+/* sampler epilogue: MinMaxScaler.inverse_transform (float64 min_/scale_, fp32 data) + np.trim_zeros + np.round
+ * (half-even) + astype(int) + 0 -> 1, src/generate.py:59-63.  out rows are zero-padded; len_out = lengths. */
+int wfd_sample_post(const float* Y, int ldy, int M, int S, const double* min_, const double* scale_, int* out, int ldo,
+                    int* len_out, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* WFDGAN_H */

@@ -1,0 +1,93 @@
+"""GPU: the fp32 MFMA GEMM core and the implicit-GEMM conv against fp64 torch references (through the C-ABI)."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _run_gemm(layout, M, N, K, lda_pad=0, ldb_pad=0, splits=None, seed=0):
+    from wfd_gan_amd._lib import lib
+    L = lib()
+    g = torch.Generator().manual_seed(seed)
+    dev = "cuda:0"
+    if layout == 0:
+        a_shape, b_shape = (M, K), (N, K)
+    elif layout == 1:
+        a_shape, b_shape = (M, K), (K, N)
+    else:
+        a_shape, b_shape = (K, M), (K, N)
+    A = torch.randn(a_shape[0], a_shape[1] + lda_pad, generator=g)
+    B = torch.randn(b_shape[0], b_shape[1] + ldb_pad, generator=g)
+    Ad, Bd = A.to(dev), B.to(dev)
+    Av, Bv = A[:, : a_shape[1]].double(), B[:, : b_shape[1]].double()
+    ref = {0: lambda: Av @ Bv.T, 1: lambda: Av @ Bv, 2: lambda: Av.T @ Bv}[layout]()
+    ns = splits or L.gemm_pick_splits(M, N, K)
+    ldp = (N + 3) // 4 * 4
+    P = torch.full((ns, M, ldp), float("nan"), device=dev)
+    L.gemm_f32(layout, Ad.data_ptr(), A.shape[1], Bd.data_ptr(), B.shape[1], P.data_ptr(), ldp, M * ldp, M, N, K, ns,
+               torch.cuda.current_stream().cuda_stream)
+    torch.cuda.synchronize()
+    out = P[:, :, :N].double().sum(0).cpu()
+    err = (out - ref).abs().max().item()
+    scale = ref.abs().max().item()
+    return err / scale
+
+
+@pytest.mark.parametrize("layout", [0, 1, 2])
+@pytest.mark.parametrize("shape", [(64, 512, 600), (128, 2048, 1501), (64, 1401, 2048), (8, 41, 21), (128, 1401, 2048),
+                                   (2048, 1501, 256), (33, 65, 31), (1, 1, 1)])
+def test_gemm_shapes(layout, shape):
+    M, N, K = shape
+    # tolerance: f32 fma chain, error ~ 1e-7 * sqrt(K) * |a||b| relative to max|C| ~ sqrt(K)
+    assert _run_gemm(layout, M, N, K) < 2e-5
+
+
+@pytest.mark.parametrize("layout", [0, 1, 2])
+def test_gemm_unaligned_ld(layout):
+    # leading dimensions that are not multiples of 4 take the scalar-load path (W1 is (2048, 1501))
+    assert _run_gemm(layout, 70, 130, 1501 if layout != 2 else 77, lda_pad=1, ldb_pad=3) < 2e-5
+    assert _run_gemm(layout, 64, 64, 64, lda_pad=0, ldb_pad=1, splits=2) < 2e-5
+
+
+def test_gemm_asymmetric_identity():
+    """A = I with an asymmetric B catches a transposed C/D fragment map."""
+    from wfd_gan_amd._lib import lib
+    L = lib()
+    n = 64
+    A = torch.eye(n, device="cuda:0")
+    B = (torch.arange(n * n, dtype=torch.float32).reshape(n, n) % 97).to("cuda:0")
+    P = torch.zeros(n, n, device="cuda:0")
+    st = torch.cuda.current_stream().cuda_stream
+    L.gemm_f32(1, A.data_ptr(), n, B.data_ptr(), n, P.data_ptr(), n, 0, n, n, n, 1, st)
+    torch.cuda.synchronize()
+    assert torch.equal(P, B)
+    L.gemm_f32(0, A.data_ptr(), n, B.data_ptr(), n, P.data_ptr(), n, 0, n, n, n, 1, st)
+    torch.cuda.synchronize()
+    assert torch.equal(P, B.T.contiguous())
+    L.gemm_f32(2, B.data_ptr(), n, A.data_ptr(), n, P.data_ptr(), n, 0, n, n, n, 1, st)
+    torch.cuda.synchronize()
+    assert torch.equal(P, B.T.contiguous())
+
+
+@pytest.mark.parametrize("cfg", [(4, 50, 32, 64), (2, 22, 128, 128), (3, 3, 128, 256), (2, 175, 64, 64)])
+@pytest.mark.parametrize("pad", [3, 4])
+def test_conv8_implicit_gemm(cfg, pad):
+    from wfd_gan_amd._lib import lib
+    import torch.nn.functional as F
+    L = lib()
+    Bn, Ln, Cin, Cout = cfg
+    g = torch.Generator().manual_seed(1)
+    x = torch.randn(Bn, Cin, Ln, generator=g)
+    w = torch.randn(Cout, Cin, 8, generator=g)
+    ref = F.conv1d(F.pad(x.double(), (pad, 7 - pad)), w.double())        # (Bn, Cout, Ln)
+    xcl = x.permute(0, 2, 1).contiguous().to("cuda:0")                   # channels-last
+    wp = w.permute(0, 2, 1).reshape(Cout, 8 * Cin).contiguous().to("cuda:0")
+    M = Bn * Ln
+    ns = L.gemm_pick_splits(M, Cout, 8 * Cin)
+    P = torch.zeros(ns, M, Cout, device="cuda:0")
+    L.conv8_gemm_f32(xcl.data_ptr(), Bn, Ln, Cin, pad, wp.data_ptr(), Cout, P.data_ptr(), Cout, M * Cout, ns,
+                     torch.cuda.current_stream().cuda_stream)
+    torch.cuda.synchronize()
+    out = P.double().sum(0).view(Bn, Ln, Cout).permute(0, 2, 1).cpu()
+    assert (out - ref).abs().max().item() / ref.abs().max().item() < 2e-5

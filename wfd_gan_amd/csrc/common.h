@@ -1,0 +1,43 @@
+// Shared helpers for the wfd-gan MI355X (gfx950) kernels.  CDNA4 only: wave = 64 lanes.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#define WFD_OK 0
+#define WFD_ERR_ARG 1
+#define WFD_ERR_LAUNCH 2
+#define WFD_ERR_WORKSPACE 3
+
+#define WFD_CHECK_LAUNCH()                         \
+    do {                                           \
+        hipError_t e__ = hipGetLastError();        \
+        if (e__ != hipSuccess) return WFD_ERR_LAUNCH; \
+    } while (0)
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+static inline int cdiv(long a, long b) { return (int)((a + b - 1) / b); }
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+    return v;
+}
+
+// block-wide sum for blockDim.x multiple of 64, <= 1024; scratch >= 16 floats of LDS
+__device__ __forceinline__ float block_sum(float v, float* scratch) {
+    v = wave_sum(v);
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, nw = blockDim.x >> 6;
+    __syncthreads();
+    if (lane == 0) scratch[w] = v;
+    __syncthreads();
+    float r = 0.f;
+    for (int i = 0; i < nw; ++i) r += scratch[i];
+    return r;
+}

@@ -1,0 +1,520 @@
+// Fused epilogue / reduction kernels of the MLP Generator + Discriminator step (gfx950).
+//
+// Every kernel here consumes the split-K slabs P[z][M][ldp] written by gemm.hip, summing them in fixed order
+// (deterministic) while applying the math that follows the contraction in the reference:
+//   bias + ReLU / sigmoid / affine(BN-eval)         src/model.py:20-34 (Generator blocks), DF layers
+//   bias + LeakyReLU(0.2) + Dropout(0.2)            src/model.py:56-66 (Discriminator)
+//   (.) o d  chain steps of the closed-form input gradient   src/mlp_df_wgan_train.py:203-213 (autograd.grad)
+//   row-wise ||g||^2, the W-div / WGAN-GP penalty and its gradient seed   :207-215, src/utils.py:82-83
+//   BatchNorm1d(eps=0.8) training forward / backward  src/model.py:23
+//   sigmoid + learned-length tail mask              src/model.py:42-47
+//   RMSprop                                          src/mlp_df_wgan_train.py:163-164 (torch defaults)
+// All are HBM/L2-bound streaming kernels: coalesced along the feature dimension, wave-reduced where a row or a
+// column is reduced.
+#include "common.h"
+
+namespace {
+
+__device__ __forceinline__ float slab_sum(const float* __restrict__ P, int ns, long ss, long idx) {
+    float a = P[idx];
+    for (int z = 1; z < ns; ++z) a += P[(long)z * ss + idx];
+    return a;
+}
+
+__device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + __expf(-x)); }
+
+// ---------------------------------------------------------------------------------------------------------
+// out[m][n] = act(sumP * scale[n] + shift[n]);  act: 0 none, 1 relu, 2 elu, 3 sigmoid
+__global__ void ep_affine_act_kernel(const float* __restrict__ P, int ns, long ss, int ldp, int M, int N,
+                                     const float* __restrict__ scale, const float* __restrict__ shift, int act,
+                                     float* __restrict__ out, int ldo) {
+    const int n = blockIdx.x * blockDim.x + threadIdx.x;
+    if (n >= N) return;
+    const float sc = scale ? scale[n] : 1.f, sh = shift ? shift[n] : 0.f;
+    for (int m = blockIdx.y; m < M; m += gridDim.y) {
+        float v = slab_sum(P, ns, ss, (long)m * ldp + n);
+        v = scale ? __fmaf_rn(v, sc, sh) : v + sh;
+        if (act == 1) v = fmaxf(v, 0.f);
+        else if (act == 2) v = v > 0.f ? v : expm1f(v);
+        else if (act == 3) v = 1.0f / (1.0f + expf(-v));
+        out[(long)m * ldo + n] = v;
+    }
+}
+
+// Discriminator hidden layer: z = sumP + b; h = leaky(z) * mask; d = mask * (z > 0 ? 1 : slope)
+__global__ void ep_lrelu_drop_kernel(const float* __restrict__ P, int ns, long ss, int ldp, int M, int N,
+                                     const float* __restrict__ bias, const float* __restrict__ mask, int ldmask,
+                                     float slope, float* __restrict__ H, int ldh, float* __restrict__ D, int ldd) {
+    const int n = blockIdx.x * blockDim.x + threadIdx.x;
+    if (n >= N) return;
+    const float b = bias[n];
+    for (int m = blockIdx.y; m < M; m += gridDim.y) {
+        const float z = slab_sum(P, ns, ss, (long)m * ldp + n) + b;
+        const float mk = mask[(long)m * ldmask + n];
+        const float lr = z > 0.f ? z : z * slope;
+        H[(long)m * ldh + n] = lr * mk;
+        D[(long)m * ldd + n] = z > 0.f ? mk : mk * slope;
+    }
+}
+
+// Discriminator head (N = 1 GEMV) + start of the input-gradient chain.  One workgroup per row.
+//   v[m] = <H3[m], w4> + b4;  delta3[m] = w4 o D3[m];  delta3s[m] = rowscale[m] * delta3[m]
+__global__ void d_head_kernel(const float* __restrict__ H3, int ldh, const float* __restrict__ D3, int ldd,
+                              const float* __restrict__ w4, const float* __restrict__ b4, int K,
+                              const float* __restrict__ rowscale, float* __restrict__ v,
+                              float* __restrict__ delta, float* __restrict__ delta_s, int ldo) {
+    __shared__ float red[16];
+    const int m = blockIdx.x;
+    float acc = 0.f;
+    for (int k = threadIdx.x; k < K; k += blockDim.x) {
+        const float w = w4[k];
+        acc = __fmaf_rn(H3[(long)m * ldh + k], w, acc);
+        const float dl = w * D3[(long)m * ldd + k];
+        delta[(long)m * ldo + k] = dl;
+        if (delta_s) delta_s[(long)m * ldo + k] = dl * rowscale[m];
+    }
+    acc = block_sum(acc, red);
+    if (threadIdx.x == 0) v[m] = acc + b4[0];
+}
+
+// out = sumP * f(D) * colscale;  dmode: 0 no D, 1 multiply by D, 2 multiply by (D > 0), 3 ELU' from its output
+// (D > 0 ? 1 : D + 1).  Optional second copy out2 = out * rowscale[m].
+__global__ void ep_mul_kernel(const float* __restrict__ P, int ns, long ss, int ldp, int M, int N,
+                              const float* __restrict__ D, int ldd, int dmode, const float* __restrict__ colscale,
+                              const float* __restrict__ rowscale, float* __restrict__ out, float* __restrict__ out2,
+                              int ldo) {
+    const int n = blockIdx.x * blockDim.x + threadIdx.x;
+    if (n >= N) return;
+    const float cs = colscale ? colscale[n] : 1.f;
+    for (int m = blockIdx.y; m < M; m += gridDim.y) {
+        float v = slab_sum(P, ns, ss, (long)m * ldp + n);
+        if (dmode == 1) v *= D[(long)m * ldd + n];
+        else if (dmode == 2) v = D[(long)m * ldd + n] > 0.f ? v : 0.f;
+        else if (dmode == 3) { const float y = D[(long)m * ldd + n]; v = y > 0.f ? v : v * (y + 1.f); }
+        v *= cs;
+        out[(long)m * ldo + n] = v;
+        if (out2) out2[(long)m * ldo + n] = v * rowscale[m];
+    }
+}
+
+// Penalty on one row of the input gradient g = sumP[m][0..S): n = ||g||^2.
+//   mode 0 (W-div, k=2, p=6):  pen[m] = n^3,              seed = 6 n^2 invB * g
+//   mode 1 (WGAN-GP):          pen[m] = (sqrt(n) - 1)^2,  seed = 2 lambda invB (sqrt(n)-1)/sqrt(n) * g
+// seed (= d loss / d g) is written to GH[m][0..S).  One workgroup per row.
+__global__ void ep_penalty_row_kernel(const float* __restrict__ P, int ns, long ss, int ldp, int S, int mode,
+                                      float invB, float lambda, float* __restrict__ nsq, float* __restrict__ pen,
+                                      float* __restrict__ GH, int ldg) {
+    __shared__ float red[16];
+    extern __shared__ float grow[];
+    const int m = blockIdx.x;
+    float acc = 0.f;
+    for (int j = threadIdx.x; j < S; j += blockDim.x) {
+        const float g = slab_sum(P, ns, ss, (long)m * ldp + j);
+        grow[j] = g;
+        acc = __fmaf_rn(g, g, acc);
+    }
+    const float n = block_sum(acc, red);
+    float coef, pv;
+    if (mode == 0) {
+        pv = n * n * n;
+        coef = 6.f * n * n * invB;
+    } else {
+        const float nr = sqrtf(n);
+        pv = (nr - 1.f) * (nr - 1.f);
+        coef = nr > 0.f ? 2.f * lambda * invB * (nr - 1.f) / nr : 0.f;
+    }
+    if (threadIdx.x == 0) { nsq[m] = n; pen[m] = pv; }
+    for (int j = threadIdx.x; j < S; j += blockDim.x) GH[(long)m * ldg + j] = coef * grow[j];
+}
+
+// out[n] (+)= sum_m X[m][n] * (rowscale ? rowscale[m] : 1)   (thread per column, coalesced)
+__global__ void colsum_kernel(const float* __restrict__ X, int ldx, int M, int N, const float* __restrict__ rowscale,
+                              float* __restrict__ out, int accumulate) {
+    const int n = blockIdx.x * blockDim.x + threadIdx.x;
+    if (n >= N) return;
+    float a = 0.f;
+    for (int m = 0; m < M; ++m) a += X[(long)m * ldx + n] * (rowscale ? rowscale[m] : 1.f);
+    out[n] = accumulate ? out[n] + a : a;
+}
+
+// RMSprop (torch defaults: alpha .99, eps 1e-8, no momentum, not centered, wd 0), one flat pass
+__global__ void rmsprop_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ sq, long n,
+                               float lr, float alpha, float eps, float gscale) {
+    const long stride = (long)gridDim.x * blockDim.x * 4;
+    for (long i = ((long)blockIdx.x * blockDim.x + threadIdx.x) * 4; i < n; i += stride) {
+        if (i + 3 < n) {
+            float4 gv = *reinterpret_cast<const float4*>(g + i);
+            float4 sv = *reinterpret_cast<const float4*>(sq + i);
+            float4 pv = *reinterpret_cast<const float4*>(p + i);
+            gv.x *= gscale; gv.y *= gscale; gv.z *= gscale; gv.w *= gscale;
+            sv.x = sv.x * alpha + (1.f - alpha) * gv.x * gv.x;
+            sv.y = sv.y * alpha + (1.f - alpha) * gv.y * gv.y;
+            sv.z = sv.z * alpha + (1.f - alpha) * gv.z * gv.z;
+            sv.w = sv.w * alpha + (1.f - alpha) * gv.w * gv.w;
+            pv.x -= lr * gv.x / (sqrtf(sv.x) + eps);
+            pv.y -= lr * gv.y / (sqrtf(sv.y) + eps);
+            pv.z -= lr * gv.z / (sqrtf(sv.z) + eps);
+            pv.w -= lr * gv.w / (sqrtf(sv.w) + eps);
+            *reinterpret_cast<float4*>(sq + i) = sv;
+            *reinterpret_cast<float4*>(p + i) = pv;
+        } else {
+            for (long j = i; j < n; ++j) {
+                const float gg = g[j] * gscale;
+                const float s = sq[j] * alpha + (1.f - alpha) * gg * gg;
+                sq[j] = s;
+                p[j] -= lr * gg / (sqrtf(s) + eps);
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// BatchNorm1d training forward, split so that data-parallel ranks can combine statistics between the halves.
+// stats kernel: Z = sumP + bias; per-column local mean and M2 = sum (z - mean)^2 (two passes, no cancellation).
+// blockDim = (64 columns, 4 row groups).
+__global__ void bn_stats_kernel(const float* __restrict__ P, int ns, long ss, int ldp, int M, int N,
+                                const float* __restrict__ bias, float* __restrict__ Z, int ldz,
+                                float* __restrict__ mean, float* __restrict__ m2) {
+    __shared__ float red[4][64];
+    const int n = blockIdx.x * 64 + threadIdx.x, rg = threadIdx.y;
+    const bool ok = n < N;
+    const float b = ok && bias ? bias[n] : 0.f;
+    float s = 0.f;
+    if (ok)
+        for (int m = rg; m < M; m += 4) {
+            const float z = slab_sum(P, ns, ss, (long)m * ldp + n) + b;
+            Z[(long)m * ldz + n] = z;
+            s += z;
+        }
+    red[rg][threadIdx.x] = s;
+    __syncthreads();
+    const float mu = (red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x]) / (float)M;
+    __syncthreads();
+    float q = 0.f;
+    if (ok)
+        for (int m = rg; m < M; m += 4) {
+            const float d = Z[(long)m * ldz + n] - mu;
+            q = __fmaf_rn(d, d, q);
+        }
+    red[rg][threadIdx.x] = q;
+    __syncthreads();
+    if (ok && rg == 0) {
+        mean[n] = mu;
+        m2[n] = red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x];
+    }
+}
+
+// apply: var = m2 / count (biased); xhat = (z - mean) * rsqrt(var + eps); h = relu(gamma * xhat + beta).
+// running stats: rm = (1-mom) rm + mom mean; rv = (1-mom) rv + mom * m2 / (count - 1), applied nupd times
+// (the G-step re-runs the same forward on the same batch: src/mlp_df_wgan_train.py:196,240).
+__global__ void bn_apply_relu_kernel(const float* __restrict__ Z, int ldz, int M, int N, const float* __restrict__ mean,
+                                     const float* __restrict__ m2, float count, float eps,
+                                     const float* __restrict__ gamma, const float* __restrict__ beta,
+                                     float* __restrict__ XH, float* __restrict__ H, int ldo,
+                                     float* __restrict__ invstd_out, float* __restrict__ rmean, float* __restrict__ rvar,
+                                     float momentum, int nupd) {
+    const int n = blockIdx.x * blockDim.x + threadIdx.x;
+    if (n >= N) return;
+    const float mu = mean[n], var = m2[n] / count;
+    const float istd = 1.0f / sqrtf(var + eps);
+    const float ga = gamma[n], be = beta[n];
+    for (int m = blockIdx.y; m < M; m += gridDim.y) {
+        const float xh = (Z[(long)m * ldz + n] - mu) * istd;
+        XH[(long)m * ldo + n] = xh;
+        H[(long)m * ldo + n] = fmaxf(__fmaf_rn(xh, ga, be), 0.f);
+    }
+    if (blockIdx.y == 0) {
+        invstd_out[n] = istd;
+        if (rmean) {
+            const float uv = m2[n] / (count - 1.f);
+            float rm = rmean[n], rv = rvar[n];
+            for (int u = 0; u < nupd; ++u) {
+                rm = (1.f - momentum) * rm + momentum * mu;
+                rv = (1.f - momentum) * rv + momentum * uv;
+            }
+            rmean[n] = rm;
+            rvar[n] = rv;
+        }
+    }
+}
+
+__global__ void bn_running_update_kernel(const float* __restrict__ mean, const float* __restrict__ m2, float count,
+                                         int N, float* __restrict__ rmean, float* __restrict__ rvar, float momentum,
+                                         int nupd) {
+    const int n = blockIdx.x * blockDim.x + threadIdx.x;
+    if (n >= N) return;
+    const float mu = mean[n], uv = m2[n] / (count - 1.f);
+    float rm = rmean[n], rv = rvar[n];
+    for (int u = 0; u < nupd; ++u) {
+        rm = (1.f - momentum) * rm + momentum * mu;
+        rv = (1.f - momentum) * rv + momentum * uv;
+    }
+    rmean[n] = rm;
+    rvar[n] = rv;
+}
+
+// BatchNorm backward through ReLU.  dy = sumP o [H > 0].
+//  phase & 1: sums[0][n] = sum_m dy, sums[1][n] = sum_m dy * xhat   (local; DP ranks all-reduce them)
+//  phase & 2: dz = gamma * invstd * (dy - sums0/count - xhat * sums1/count);  dgamma = sums1; dbeta = sums0;
+//             dbias[n] = sum_m dz (the Linear bias in front of BN; mathematically 0, computed as autograd does)
+// thread per column.
+__global__ void bn_bwd_kernel(const float* __restrict__ P, int ns, long ss, int ldp, int M, int N,
+                              const float* __restrict__ H, const float* __restrict__ XH, int ldh,
+                              const float* __restrict__ gamma, const float* __restrict__ invstd, float count,
+                              float* __restrict__ sums, float* __restrict__ DZ, int lddz, float* __restrict__ dgamma,
+                              float* __restrict__ dbeta, float* __restrict__ dbias, int phase) {
+    const int n = blockIdx.x * blockDim.x + threadIdx.x;
+    if (n >= N) return;
+    if (phase & 1) {
+        float s0 = 0.f, s1 = 0.f;
+        for (int m = 0; m < M; ++m) {
+            const long o = (long)m * ldh + n;
+            const float dy = H[o] > 0.f ? slab_sum(P, ns, ss, (long)m * ldp + n) : 0.f;
+            s0 += dy;
+            s1 = __fmaf_rn(dy, XH[o], s1);
+        }
+        sums[n] = s0;
+        sums[N + n] = s1;
+    }
+    if (phase & 2) {
+        const float s0 = sums[n], s1 = sums[N + n];
+        const float k = gamma[n] * invstd[n], a0 = s0 / count, a1 = s1 / count;
+        float sb = 0.f;
+        for (int m = 0; m < M; ++m) {
+            const long o = (long)m * ldh + n;
+            const float dy = H[o] > 0.f ? slab_sum(P, ns, ss, (long)m * ldp + n) : 0.f;
+            const float dz = k * (dy - a0 - XH[o] * a1);
+            DZ[(long)m * lddz + n] = dz;
+            sb += dz;
+        }
+        dgamma[n] = s1;
+        dbeta[n] = s0;
+        dbias[n] = sb;
+    }
+}
+
+// Generator output: y = sigmoid(sumP + b); bl = y0 * (smax - smin) + smin (two fp32 roundings, as torch does);
+// idx = trunc(bl) + 1; out[j] = j < idx ? y[j] : 0.  One workgroup per row.  idx >= S (the reference raises
+// IndexError there) sets *err and clamps.
+__global__ void ep_sigmoid_lenmask_kernel(const float* __restrict__ P, int ns, long ss, int ldp, int S,
+                                          const float* __restrict__ bias, float range, float smin,
+                                          float* __restrict__ out, int ldo, int* __restrict__ idx_out,
+                                          int* __restrict__ err) {
+    const int m = blockIdx.x;
+    const float y0 = 1.0f / (1.0f + expf(-(slab_sum(P, ns, ss, (long)m * ldp) + bias[0])));
+    const float bl = __fadd_rn(__fmul_rn(y0, range), smin);
+    long idx = (long)bl + 1;
+    if (idx >= S || idx < 0) {
+        if (threadIdx.x == 0) atomicOr(err, 1);
+        idx = idx < 0 ? 0 : S;
+    }
+    if (threadIdx.x == 0) idx_out[m] = (int)idx;
+    for (int j = threadIdx.x; j < S; j += blockDim.x) {
+        float y = 0.f;
+        if (j < idx) y = 1.0f / (1.0f + expf(-(slab_sum(P, ns, ss, (long)m * ldp + j) + bias[j])));
+        out[(long)m * ldo + j] = y;
+    }
+}
+
+// Gradient at the generator's last pre-activation (thread per column j, loops rows):
+//   dfake[m][j] = dscale * sumP[m][j] (D path, dscale = -1/B) + (j >= 1 ? dDF[m][j-1] : 0)
+//   dz[m][j]    = j < idx[m] ? dfake * y (1 - y) : 0, y = fake[m][j];   dbias[j] = sum_m dz
+__global__ void g_out_bwd_kernel(const float* __restrict__ P, int ns, long ss, int ldp, int M, int S, float dscale,
+                                 const float* __restrict__ dDF, int lddf, const float* __restrict__ fake, int ldf,
+                                 const int* __restrict__ idx, float* __restrict__ DZ, int lddz,
+                                 float* __restrict__ dbias) {
+    const int j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= S) return;
+    float sb = 0.f;
+    for (int m = 0; m < M; ++m) {
+        float dz = 0.f;
+        if (j < idx[m]) {
+            float df = dscale * slab_sum(P, ns, ss, (long)m * ldp + j);
+            if (dDF && j >= 1) df += dDF[(long)m * lddf + j - 1];
+            const float y = fake[(long)m * ldf + j];
+            dz = df * y * (1.f - y);
+        }
+        DZ[(long)m * lddz + j] = dz;
+        sb += dz;
+    }
+    dbias[j] = sb;
+}
+
+// D-step scalars.  v rows [0,B) real, [B,2B) fake; pen rows likewise (W-div) or B interpolate rows (GP).
+// out: [0] d_loss [1] penalty [2] w_dist [3] mean_rv [4] mean_fv ; acc[0..2] += d_loss, w_dist, 1 (epoch sums)
+__global__ void d_loss_kernel(const float* __restrict__ v, const float* __restrict__ pen, int B, int npen, float invB,
+                              float pen_weight, float* __restrict__ out, float* __restrict__ acc) {
+    __shared__ float red[16];
+    float sr = 0.f, sf = 0.f, sp = 0.f;
+    for (int i = threadIdx.x; i < B; i += blockDim.x) { sr += v[i]; sf += v[B + i]; }
+    for (int i = threadIdx.x; i < npen; i += blockDim.x) sp += pen[i];
+    sr = block_sum(sr, red);
+    sf = block_sum(sf, red);
+    sp = block_sum(sp, red);
+    if (threadIdx.x == 0) {
+        const float mr = sr * invB, mf = sf * invB, pv = sp * invB;
+        const float dl = -mr + mf + pen_weight * pv;
+        out[0] = dl; out[1] = pv; out[2] = mr - mf; out[3] = mr; out[4] = mf;
+        if (acc) { acc[0] += dl; acc[1] += mr - mf; acc[2] += 1.f; }
+    }
+}
+
+// G-step head scalars: g_loss = -mean(fv); nsel = #{fv > 0}.  out[0] g_loss, out[1] nsel
+__global__ void g_head_kernel(const float* __restrict__ fv, int B, float invB, float* __restrict__ out) {
+    __shared__ float red[16];
+    float s = 0.f, c = 0.f;
+    for (int i = threadIdx.x; i < B; i += blockDim.x) { s += fv[i]; c += fv[i] > 0.f ? 1.f : 0.f; }
+    s = block_sum(s, red);
+    c = block_sum(c, red);
+    if (threadIdx.x == 0) { out[0] = -s * invB; out[1] = c; }
+}
+
+}  // namespace
+
+// ---- internal launchers (used by step.hip) and their extern "C" faces -----------------------------------------
+static inline dim3 col_grid(int N, int M, int bx = 256) { return dim3(cdiv(N, bx), M < 64 ? M : 64); }
+
+extern "C" {
+
+int wfd_ep_affine_act(const float* P, int ns, long ss, int ldp, int M, int N, const float* scale, const float* shift,
+                      int act, float* out, int ldo, void* stream) {
+    if (!P || !out || M <= 0 || N <= 0) return WFD_ERR_ARG;
+    hipLaunchKernelGGL(ep_affine_act_kernel, col_grid(N, M), dim3(256), 0, (hipStream_t)stream, P, ns, ss, ldp, M, N,
+                       scale, shift, act, out, ldo);
+    WFD_CHECK_LAUNCH();
+    return WFD_OK;
+}
+
+int wfd_ep_lrelu_drop(const float* P, int ns, long ss, int ldp, int M, int N, const float* bias, const float* mask,
+                      int ldmask, float slope, float* H, int ldh, float* D, int ldd, void* stream) {
+    if (!P || !bias || !mask || !H || !D) return WFD_ERR_ARG;
+    hipLaunchKernelGGL(ep_lrelu_drop_kernel, col_grid(N, M), dim3(256), 0, (hipStream_t)stream, P, ns, ss, ldp, M, N,
+                       bias, mask, ldmask, slope, H, ldh, D, ldd);
+    WFD_CHECK_LAUNCH();
+    return WFD_OK;
+}
+
+int wfd_d_head(const float* H3, int ldh, const float* D3, int ldd, const float* w4, const float* b4, int M, int K,
+               const float* rowscale, float* v, float* delta, float* delta_s, int ldo, void* stream) {
+    if (!H3 || !D3 || !w4 || !b4 || !v || !delta) return WFD_ERR_ARG;
+    if (delta_s && !rowscale) return WFD_ERR_ARG;
+    hipLaunchKernelGGL(d_head_kernel, dim3(M), dim3(256), 0, (hipStream_t)stream, H3, ldh, D3, ldd, w4, b4, K, rowscale,
+                       v, delta, delta_s, ldo);
+    WFD_CHECK_LAUNCH();
+    return WFD_OK;
+}
+
+int wfd_ep_mul(const float* P, int ns, long ss, int ldp, int M, int N, const float* D, int ldd, int dmode,
+               const float* colscale, const float* rowscale, float* out, float* out2, int ldo, void* stream) {
+    if (!P || !out || (dmode && !D) || (out2 && !rowscale)) return WFD_ERR_ARG;
+    hipLaunchKernelGGL(ep_mul_kernel, col_grid(N, M), dim3(256), 0, (hipStream_t)stream, P, ns, ss, ldp, M, N, D, ldd,
+                       dmode, colscale, rowscale, out, out2, ldo);
+    WFD_CHECK_LAUNCH();
+    return WFD_OK;
+}
+
+int wfd_ep_penalty_row(const float* P, int ns, long ss, int ldp, int M, int S, int mode, float invB, float lambda,
+                       float* nsq, float* pen, float* GH, int ldg, void* stream) {
+    if (!P || !nsq || !pen || !GH || S <= 0 || (size_t)S * 4 > 60000) return WFD_ERR_ARG;
+    hipLaunchKernelGGL(ep_penalty_row_kernel, dim3(M), dim3(256), (size_t)S * sizeof(float), (hipStream_t)stream, P, ns,
+                       ss, ldp, S, mode, invB, lambda, nsq, pen, GH, ldg);
+    WFD_CHECK_LAUNCH();
+    return WFD_OK;
+}
+
+int wfd_colsum(const float* X, int ldx, int M, int N, const float* rowscale, float* out, int accumulate,
+               void* stream) {
+    if (!X || !out) return WFD_ERR_ARG;
+    hipLaunchKernelGGL(colsum_kernel, dim3(cdiv(N, 64)), dim3(64), 0, (hipStream_t)stream, X, ldx, M, N, rowscale, out,
+                       accumulate);
+    WFD_CHECK_LAUNCH();
+    return WFD_OK;
+}
+
+int wfd_rmsprop(float* p, const float* g, float* sq, long n, float lr, float alpha, float eps, float gscale,
+                void* stream) {
+    if (!p || !g || !sq || n <= 0) return WFD_ERR_ARG;
+    if ((((uintptr_t)p | (uintptr_t)g | (uintptr_t)sq) & 15) != 0) return WFD_ERR_ARG;
+    long blocks = (n / 4 + 255) / 256;
+    if (blocks > 2048) blocks = 2048;
+    if (blocks < 1) blocks = 1;
+    hipLaunchKernelGGL(rmsprop_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, p, g, sq, n, lr, alpha,
+                       eps, gscale);
+    WFD_CHECK_LAUNCH();
+    return WFD_OK;
+}
+
+int wfd_bn_stats(const float* P, int ns, long ss, int ldp, int M, int N, const float* bias, float* Z, int ldz,
+                 float* mean, float* m2, void* stream) {
+    if (!P || !Z || !mean || !m2) return WFD_ERR_ARG;
+    hipLaunchKernelGGL(bn_stats_kernel, dim3(cdiv(N, 64)), dim3(64, 4), 0, (hipStream_t)stream, P, ns, ss, ldp, M, N,
+                       bias, Z, ldz, mean, m2);
+    WFD_CHECK_LAUNCH();
+    return WFD_OK;
+}
+
+int wfd_bn_apply_relu(const float* Z, int ldz, int M, int N, const float* mean, const float* m2, float count, float eps,
+                      const float* gamma, const float* beta, float* XH, float* H, int ldo, float* invstd, float* rmean,
+                      float* rvar, float momentum, int nupd, void* stream) {
+    if (!Z || !mean || !m2 || !gamma || !beta || !XH || !H || !invstd) return WFD_ERR_ARG;
+    hipLaunchKernelGGL(bn_apply_relu_kernel, col_grid(N, M, 64), dim3(64), 0, (hipStream_t)stream, Z, ldz, M, N, mean, m2,
+                       count, eps, gamma, beta, XH, H, ldo, invstd, rmean, rvar, momentum, nupd);
+    WFD_CHECK_LAUNCH();
+    return WFD_OK;
+}
+
+int wfd_bn_running_update(const float* mean, const float* m2, float count, int N, float* rmean, float* rvar,
+                          float momentum, int nupd, void* stream) {
+    if (!mean || !m2 || !rmean || !rvar) return WFD_ERR_ARG;
+    hipLaunchKernelGGL(bn_running_update_kernel, dim3(cdiv(N, 256)), dim3(256), 0, (hipStream_t)stream, mean, m2, count,
+                       N, rmean, rvar, momentum, nupd);
+    WFD_CHECK_LAUNCH();
+    return WFD_OK;
+}
+
+int wfd_bn_bwd(const float* P, int ns, long ss, int ldp, int M, int N, const float* H, const float* XH, int ldh,
+               const float* gamma, const float* invstd, float count, float* sums, float* DZ, int lddz, float* dgamma,
+               float* dbeta, float* dbias, int phase, void* stream) {
+    if (!P || !H || !XH || !gamma || !invstd || !sums) return WFD_ERR_ARG;
+    if ((phase & 2) && (!DZ || !dgamma || !dbeta || !dbias)) return WFD_ERR_ARG;
+    hipLaunchKernelGGL(bn_bwd_kernel, dim3(cdiv(N, 64)), dim3(64), 0, (hipStream_t)stream, P, ns, ss, ldp, M, N, H, XH,
+                       ldh, gamma, invstd, count, sums, DZ, lddz, dgamma, dbeta, dbias, phase);
+    WFD_CHECK_LAUNCH();
+    return WFD_OK;
+}
+
+int wfd_ep_sigmoid_lenmask(const float* P, int ns, long ss, int ldp, int M, int S, const float* bias, float range,
+                           float smin, float* out, int ldo, int* idx, int* err, void* stream) {
+    if (!P || !bias || !out || !idx || !err) return WFD_ERR_ARG;
+    hipLaunchKernelGGL(ep_sigmoid_lenmask_kernel, dim3(M), dim3(256), 0, (hipStream_t)stream, P, ns, ss, ldp, S, bias,
+                       range, smin, out, ldo, idx, err);
+    WFD_CHECK_LAUNCH();
+    return WFD_OK;
+}
+
+int wfd_g_out_bwd(const float* P, int ns, long ss, int ldp, int M, int S, float dscale, const float* dDF, int lddf,
+                  const float* fake, int ldf, const int* idx, float* DZ, int lddz, float* dbias, void* stream) {
+    if (!P || !fake || !idx || !DZ || !dbias) return WFD_ERR_ARG;
+    hipLaunchKernelGGL(g_out_bwd_kernel, dim3(cdiv(S, 64)), dim3(64), 0, (hipStream_t)stream, P, ns, ss, ldp, M, S,
+                       dscale, dDF, lddf, fake, ldf, idx, DZ, lddz, dbias);
+    WFD_CHECK_LAUNCH();
+    return WFD_OK;
+}
+
+int wfd_d_loss(const float* v, const float* pen, int B, int npen, float invB, float pen_weight, float* out, float* acc,
+               void* stream) {
+    if (!v || !pen || !out) return WFD_ERR_ARG;
+    hipLaunchKernelGGL(d_loss_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, v, pen, B, npen, invB, pen_weight, out,
+                       acc);
+    WFD_CHECK_LAUNCH();
+    return WFD_OK;
+}
+
+int wfd_g_head(const float* fv, int B, float invB, float* out, void* stream) {
+    if (!fv || !out) return WFD_ERR_ARG;
+    hipLaunchKernelGGL(g_head_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, fv, B, invB, out);
+    WFD_CHECK_LAUNCH();
+    return WFD_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,273 @@
+// fp32-operand MFMA GEMM core for gfx950 (v_mfma_f32_32x32x2_f32: exact f32 products, f32 accumulate).
+//
+// One kernel template covers every dense contraction on the wfd-gan hot path:
+//   NT  P[m][n] = sum_k A[m][k] * B[n][k]     forward Linear (weights are (out,in) row-major), penalty t-chain
+//   NN  P[m][n] = sum_k A[m][k] * B[k][n]     input-gradient chains  (delta * W)
+//   TN  P[m][n] = sum_k A[k][m] * B[k][n]     weight gradients (reduction over batch rows)
+//   NT + IM2COL: A is a channels-last activation [B][L][Cin] read as the im2col matrix of a k=8 "SAME" conv,
+//                A[m][k] = X[m*Cin + k - pad*Cin] masked by 0 <= (m % L) + k/Cin - pad < L.
+// Raw products only: the batch dimension is tiny (64..128 rows) so the K dimension is split over gridDim.z to
+// fill 256 CUs; each split writes its own slab P[z][M][ldp] with plain stores (deterministic, no atomics) and
+// the consumer epilogue kernel (epilogues.hip / df.hip) sums the slabs in fixed order while applying the fused
+// bias / activation / dropout / BN / penalty math.
+//
+// Tile: 64x64x32 per 256-thread workgroup, 2x2 waves of one 32x32 accumulator each.  Operands are staged
+// global -> registers -> LDS (double buffered, one barrier per k-tile).  A k-contiguous operand tile is stored
+// [row][36] and read with one ds_read_b128 per 4 MFMAs (conflict-free: 36 mod 64 walks all 16 slots); an
+// m-contiguous one is stored [k][68] and read with ds_read_b32.  Lane half h of MFMA step s consumes
+// k = 8*kk + 4*h + s for BOTH operands, so the k-permutation inside a tile is consistent.
+#include "common.h"
+
+namespace {
+
+constexpr int BM = 64, BN = 64, BK = 32, NTHREADS = 256;
+constexpr int LDK = BK + 4;  // row stride of a k-contiguous tile  [64][36]
+constexpr int LDM = BM + 4;  // row stride of an m-contiguous tile [32][68]
+constexpr int TILE_F = 64 * LDK;  // 2304 floats >= 32*68 = 2176
+
+struct GemmArgs {
+    const float* A;
+    const float* B;
+    float* P;
+    int M, N, K;
+    int lda, ldb, ldp;
+    long slab_stride;   // floats between split slabs
+    int ktiles_per_split;
+    int convL, convCin, convPad;  // IM2COL only
+};
+
+// ---- global -> register staging -------------------------------------------------------------------------
+// KC = operand is k-contiguous in global memory ([rows][K], ld); else row(k)-major with the m/n index contiguous.
+template <bool KC, int VEC, bool IM2COL>
+__device__ __forceinline__ void load_tile(float (&r)[8], const float* __restrict__ G, int ld, int row0, int nrows,
+                                          int k0, int kend, int tid, int convL, int convCin, int convPad) {
+    if constexpr (KC) {
+        if constexpr (VEC == 4) {
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const int rr = (tid >> 3) + 32 * j, gk = k0 + 4 * (tid & 7), gr = row0 + rr;
+                float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+                bool ok = gr < nrows && gk < kend;
+                long off;
+                if constexpr (IM2COL) {
+                    const int l = gr % convL, t = gk / convCin;
+                    ok = ok && (unsigned)(l + t - convPad) < (unsigned)convL;
+                    off = (long)gr * convCin + gk - (long)convPad * convCin;
+                } else {
+                    off = (long)gr * ld + gk;
+                }
+                if (ok) {
+                    if (gk + 3 < kend) {
+                        v = *reinterpret_cast<const float4*>(G + off);
+                    } else {
+                        v.x = G[off];
+                        if (gk + 1 < kend) v.y = G[off + 1];
+                        if (gk + 2 < kend) v.z = G[off + 2];
+                    }
+                }
+                r[4 * j + 0] = v.x; r[4 * j + 1] = v.y; r[4 * j + 2] = v.z; r[4 * j + 3] = v.w;
+            }
+        } else {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const int rr = (tid >> 5) + 8 * j, gk = k0 + (tid & 31), gr = row0 + rr;
+                r[j] = (gr < nrows && gk < kend) ? G[(long)gr * ld + gk] : 0.f;
+            }
+        }
+    } else {
+        if constexpr (VEC == 4) {
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const int kr = (tid >> 4) + 16 * j, gk = k0 + kr, gc = row0 + 4 * (tid & 15);
+                float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (gk < kend && gc < nrows) {
+                    const long off = (long)gk * ld + gc;
+                    if (gc + 3 < nrows) {
+                        v = *reinterpret_cast<const float4*>(G + off);
+                    } else {
+                        v.x = G[off];
+                        if (gc + 1 < nrows) v.y = G[off + 1];
+                        if (gc + 2 < nrows) v.z = G[off + 2];
+                    }
+                }
+                r[4 * j + 0] = v.x; r[4 * j + 1] = v.y; r[4 * j + 2] = v.z; r[4 * j + 3] = v.w;
+            }
+        } else {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const int kr = (tid >> 6) + 4 * j, gk = k0 + kr, gc = row0 + (tid & 63);
+                r[j] = (gk < kend && gc < nrows) ? G[(long)gk * ld + gc] : 0.f;
+            }
+        }
+    }
+}
+
+template <bool KC, int VEC>
+__device__ __forceinline__ void store_tile(const float (&r)[8], float* __restrict__ S, int tid) {
+    if constexpr (KC) {
+        if constexpr (VEC == 4) {
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const int rr = (tid >> 3) + 32 * j, kq = tid & 7;
+                *reinterpret_cast<float4*>(S + rr * LDK + 4 * kq) =
+                    make_float4(r[4 * j], r[4 * j + 1], r[4 * j + 2], r[4 * j + 3]);
+            }
+        } else {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) S[((tid >> 5) + 8 * j) * LDK + (tid & 31)] = r[j];
+        }
+    } else {
+        if constexpr (VEC == 4) {
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const int kr = (tid >> 4) + 16 * j, mq = tid & 15;
+                *reinterpret_cast<float4*>(S + kr * LDM + 4 * mq) =
+                    make_float4(r[4 * j], r[4 * j + 1], r[4 * j + 2], r[4 * j + 3]);
+            }
+        } else {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) S[((tid >> 6) + 4 * j) * LDM + (tid & 63)] = r[j];
+        }
+    }
+}
+
+// fragment of MFMA steps s = 0..3 of k-group kk for the 32-row block starting at row0 (i = lane & 31, h = lane >> 5)
+template <bool KC>
+__device__ __forceinline__ f32x4 read_frag(const float* __restrict__ S, int row0, int kk, int i, int h) {
+    if constexpr (KC) {
+        return *reinterpret_cast<const f32x4*>(S + (row0 + i) * LDK + kk * 8 + 4 * h);
+    } else {
+        f32x4 v;
+        const float* p = S + (kk * 8 + 4 * h) * LDM + row0 + i;
+        v[0] = p[0]; v[1] = p[LDM]; v[2] = p[2 * LDM]; v[3] = p[3 * LDM];
+        return v;
+    }
+}
+
+template <bool AKC, bool BKC, int VA, int VB, bool IM2COL>
+__global__ __launch_bounds__(NTHREADS) void gemm_f32_kernel(GemmArgs g) {
+    __shared__ __attribute__((aligned(16))) float lds[4 * TILE_F];
+    // buffer c: A tile at lds + 2c*TILE_F, B tile right behind it
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1, i = lane & 31, h = lane >> 5;
+    const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN, z = blockIdx.z;
+    const int kbeg = z * g.ktiles_per_split * BK;
+    const int kend = min(g.K, kbeg + g.ktiles_per_split * BK);
+    const int nk = (kend > kbeg) ? (kend - kbeg + BK - 1) / BK : 0;
+
+    f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+
+    float ra[8], rb[8];
+    if (nk > 0) {
+        load_tile<AKC, VA, IM2COL>(ra, g.A, g.lda, m0, g.M, kbeg, kend, tid, g.convL, g.convCin, g.convPad);
+        load_tile<BKC, VB, false>(rb, g.B, g.ldb, n0, g.N, kbeg, kend, tid, 0, 0, 0);
+        store_tile<AKC, VA>(ra, lds, tid);
+        store_tile<BKC, VB>(rb, lds + TILE_F, tid);
+    }
+    __syncthreads();
+    int cur = 0;
+    for (int kt = 0; kt < nk; ++kt) {
+        const bool more = kt + 1 < nk;
+        if (more) {
+            const int k0 = kbeg + (kt + 1) * BK;
+            load_tile<AKC, VA, IM2COL>(ra, g.A, g.lda, m0, g.M, k0, kend, tid, g.convL, g.convCin, g.convPad);
+            load_tile<BKC, VB, false>(rb, g.B, g.ldb, n0, g.N, k0, kend, tid, 0, 0, 0);
+        }
+        const float* a_s = lds + cur * 2 * TILE_F;
+        const float* b_s = a_s + TILE_F;
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) {
+            const f32x4 a = read_frag<AKC>(a_s, wm * 32, kk, i, h);
+            const f32x4 b = read_frag<BKC>(b_s, wn * 32, kk, i, h);
+#pragma unroll
+            for (int s = 0; s < 4; ++s) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[s], b[s], acc, 0, 0, 0);
+        }
+        if (more) {
+            store_tile<AKC, VA>(ra, lds + (cur ^ 1) * 2 * TILE_F, tid);
+            store_tile<BKC, VB>(rb, lds + (cur ^ 1) * 2 * TILE_F + TILE_F, tid);
+        }
+        __syncthreads();
+        cur ^= 1;
+    }
+
+    // C/D map of the 32x32 accumulator: col = lane & 31, row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)
+    float* P = g.P + (long)z * g.slab_stride;
+    const int col = n0 + wn * 32 + i;
+    if (col < g.N) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int row = m0 + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+            if (row < g.M) P[(long)row * g.ldp + col] = acc[r];
+        }
+    }
+}
+
+template <bool AKC, bool BKC, bool IM2COL>
+int launch_gemm(const GemmArgs& g, int splits, bool va4, bool vb4, hipStream_t st) {
+    dim3 grid(cdiv(g.N, BN), cdiv(g.M, BM), splits), block(NTHREADS);
+    if (va4 && vb4) hipLaunchKernelGGL((gemm_f32_kernel<AKC, BKC, 4, 4, IM2COL>), grid, block, 0, st, g);
+    else if (va4) hipLaunchKernelGGL((gemm_f32_kernel<AKC, BKC, 4, 1, IM2COL>), grid, block, 0, st, g);
+    else if (vb4) hipLaunchKernelGGL((gemm_f32_kernel<AKC, BKC, 1, 4, IM2COL>), grid, block, 0, st, g);
+    else hipLaunchKernelGGL((gemm_f32_kernel<AKC, BKC, 1, 1, IM2COL>), grid, block, 0, st, g);
+    WFD_CHECK_LAUNCH();
+    return WFD_OK;
+}
+
+inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
+
+}  // namespace
+
+extern "C" {
+
+// Number of K splits the library would pick for an (M,N,K) product: enough workgroups to cover the 256 CUs about
+// twice, never thinner than 2 k-tiles per split.  The caller sizes the slab workspace with it.
+int wfd_gemm_pick_splits(int M, int N, int K) {
+    const int tiles = cdiv(M, BM) * cdiv(N, BN);
+    const int ktiles = cdiv(K, BK);
+    int s = 512 / (tiles > 0 ? tiles : 1);
+    if (s < 1) s = 1;
+    if (s > 16) s = 16;
+    while (s > 1 && ktiles / s < 2) --s;
+    return s;
+}
+
+// layout: 0 = NT, 1 = NN, 2 = TN.  P receives `splits` slabs of M x ldp floats, slab_stride floats apart.
+int wfd_gemm_f32(int layout, const float* A, int lda, const float* B, int ldb, float* P, int ldp, long slab_stride,
+                 int M, int N, int K, int splits, void* stream) {
+    if (!A || !B || !P || M <= 0 || N <= 0 || K <= 0 || splits < 1 || ldp < N) return WFD_ERR_ARG;
+    if (splits > 1 && slab_stride < (long)M * ldp) return WFD_ERR_ARG;
+    GemmArgs g{};
+    g.A = A; g.B = B; g.P = P; g.M = M; g.N = N; g.K = K; g.lda = lda; g.ldb = ldb; g.ldp = ldp;
+    g.slab_stride = slab_stride;
+    g.ktiles_per_split = cdiv(cdiv(K, BK), splits);
+    hipStream_t st = (hipStream_t)stream;
+    const bool va4 = aligned16(A) && (lda % 4 == 0), vb4 = aligned16(B) && (ldb % 4 == 0);
+    switch (layout) {
+        case 0: if (lda < K || ldb < K) return WFD_ERR_ARG; return launch_gemm<true, true, false>(g, splits, va4, vb4, st);
+        case 1: if (lda < K || ldb < N) return WFD_ERR_ARG; return launch_gemm<true, false, false>(g, splits, va4, vb4, st);
+        case 2: if (lda < M || ldb < N) return WFD_ERR_ARG; return launch_gemm<false, false, false>(g, splits, va4, vb4, st);
+        default: return WFD_ERR_ARG;
+    }
+}
+
+// "SAME" k=8 stride-1 conv as an implicit GEMM over a channels-last activation X[B][L][Cin]:
+//   P[b*L + l][co] = sum_{t,ci} X[b][l + t - pad][ci] * Wp[co][t*Cin + ci]      (zero outside [0,L))
+// pad = 3 for the forward conv (src/model.py:96-101: p = 7, left 3 / right 4) and 4 for its transposed
+// (input-gradient) form with flipped taps.  Cin % 4 == 0 required (Cin = 1 uses the direct kernel in df.hip).
+int wfd_conv8_gemm_f32(const float* X, int Bn, int L, int Cin, int pad, const float* Wp, int Cout, float* P, int ldp,
+                       long slab_stride, int splits, void* stream) {
+    if (!X || !Wp || !P || Bn <= 0 || L <= 0 || Cin <= 0 || (Cin & 3) || Cout <= 0 || ldp < Cout) return WFD_ERR_ARG;
+    if (!aligned16(X) || !aligned16(Wp)) return WFD_ERR_ARG;
+    GemmArgs g{};
+    g.A = X; g.B = Wp; g.P = P; g.M = Bn * L; g.N = Cout; g.K = 8 * Cin; g.lda = Cin; g.ldb = 8 * Cin; g.ldp = ldp;
+    g.slab_stride = slab_stride;
+    g.ktiles_per_split = cdiv(cdiv(g.K, BK), splits);
+    g.convL = L; g.convCin = Cin; g.convPad = pad;
+    if (splits > 1 && slab_stride < (long)g.M * ldp) return WFD_ERR_ARG;
+    return launch_gemm<true, true, true>(g, splits, true, true, (hipStream_t)stream);
+}
+
+}  // extern "C"

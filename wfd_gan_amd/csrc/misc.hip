@@ -1,0 +1,198 @@
+// Data-side kernels of the wfd-gan hot path (gfx950): batch assembly, device RNG (fast mode), burst clipping,
+// and the sampler's inverse-scale / round-half-even / trim epilogue (src/generate.py:59-63).  All HBM-bound.
+#include "common.h"
+
+namespace {
+
+// ---- Philox4x32-10 (counter-based; one 128-bit block per 4 outputs) ---------------------------------------
+__device__ __forceinline__ uint4 philox4x32_10(uint4 ctr, uint2 key) {
+    const uint32_t M0 = 0xD2511F53u, M1 = 0xCD9E8D57u, W0 = 0x9E3779B9u, W1 = 0xBB67AE85u;
+#pragma unroll
+    for (int r = 0; r < 10; ++r) {
+        const uint32_t hi0 = __umulhi(M0, ctr.x), lo0 = M0 * ctr.x;
+        const uint32_t hi1 = __umulhi(M1, ctr.z), lo1 = M1 * ctr.z;
+        ctr = make_uint4(hi1 ^ ctr.y ^ key.x, lo1, hi0 ^ ctr.w ^ key.y, lo0);
+        key.x += W0;
+        key.y += W1;
+    }
+    return ctr;
+}
+__device__ __forceinline__ float u01(uint32_t x) { return ((x >> 8) + 0.5f) * (1.0f / 16777216.0f); }
+
+// dropout keep-masks with values {0, 1/(1-p)} (what nn.Dropout multiplies by); n multiple of 4 handled generally
+__global__ void rng_dropout_mask_kernel(float* __restrict__ out, long n, float p, unsigned long long seed,
+                                        unsigned long long offset) {
+    const float keep = 1.0f / (1.0f - p);
+    const long stride = (long)gridDim.x * blockDim.x;
+    for (long q = (long)blockIdx.x * blockDim.x + threadIdx.x; q * 4 < n; q += stride) {
+        const unsigned long long c = offset + (unsigned long long)q;
+        const uint4 r = philox4x32_10(make_uint4((uint32_t)c, (uint32_t)(c >> 32), 0x6d61736bu, 0u),
+                                      make_uint2((uint32_t)seed, (uint32_t)(seed >> 32)));
+        const float v[4] = {u01(r.x) >= p ? keep : 0.f, u01(r.y) >= p ? keep : 0.f, u01(r.z) >= p ? keep : 0.f,
+                            u01(r.w) >= p ? keep : 0.f};
+        for (int k = 0; k < 4; ++k)
+            if (q * 4 + k < n) out[q * 4 + k] = v[k];
+    }
+}
+
+// standard normal into rows of a strided matrix: out[m][0..Z) (Box-Muller on Philox uniforms)
+__global__ void rng_normal_rows_kernel(float* __restrict__ out, int ld, int M, int Z, unsigned long long seed,
+                                       unsigned long long offset) {
+    const long total4 = ((long)M * Z + 3) / 4;
+    const long stride = (long)gridDim.x * blockDim.x;
+    for (long q = (long)blockIdx.x * blockDim.x + threadIdx.x; q < total4; q += stride) {
+        const unsigned long long c = offset + (unsigned long long)q;
+        const uint4 r = philox4x32_10(make_uint4((uint32_t)c, (uint32_t)(c >> 32), 0x6e6f726du, 0u),
+                                      make_uint2((uint32_t)seed, (uint32_t)(seed >> 32)));
+        const float r0 = sqrtf(-2.f * logf(u01(r.x))), r1 = sqrtf(-2.f * logf(u01(r.z)));
+        float s0, c0, s1, c1;
+        sincosf(6.283185307179586f * u01(r.y), &s0, &c0);
+        sincosf(6.283185307179586f * u01(r.w), &s1, &c1);
+        const float v[4] = {r0 * c0, r0 * s0, r1 * c1, r1 * s1};
+        for (int k = 0; k < 4; ++k) {
+            const long e = q * 4 + k;
+            if (e < (long)M * Z) out[(e / Z) * ld + (e % Z)] = v[k];
+        }
+    }
+}
+
+// Assemble one training batch on device (replaces the DataLoader + np.eye one-hot of
+// src/mlp_df_wgan_train.py:184-186):  for b < B:
+//   real[b][0..S) = X[idx[b]][0..S);  real[b][S..S+C) = onehot(y[idx[b]]);  fake[b][S..S+C) = same one-hot
+//   zin[b][Z..Z+C) = same one-hot;  labels_out[b] = y[idx[b]]
+__global__ void gather_batch_kernel(const float* __restrict__ X, int ldX, const int* __restrict__ y,
+                                    const long long* __restrict__ idx, int S, int C, float* __restrict__ real,
+                                    float* __restrict__ fake, int ldd, float* __restrict__ zin, int ldz, int Z,
+                                    int* __restrict__ labels_out) {
+    const int b = blockIdx.x;
+    const long long src = idx[b];
+    const int lab = y[src];
+    for (int j = threadIdx.x; j < S; j += blockDim.x) real[(long)b * ldd + j] = X[src * ldX + j];
+    for (int c = threadIdx.x; c < C; c += blockDim.x) {
+        const float v = c == lab ? 1.f : 0.f;
+        real[(long)b * ldd + S + c] = v;
+        if (fake) fake[(long)b * ldd + S + c] = v;
+        if (zin) zin[(long)b * ldz + Z + c] = v;
+    }
+    if (threadIdx.x == 0 && labels_out) labels_out[b] = lab;
+}
+
+// one-hot class columns for the sampler: zin[m][Z..Z+C) = onehot(labels[m])
+__global__ void onehot_rows_kernel(const int* __restrict__ labels, int M, int C, float* __restrict__ out, int ld,
+                                   int col0) {
+    const int m = blockIdx.x;
+    const int lab = labels[m];
+    for (int c = threadIdx.x; c < C; c += blockDim.x) out[(long)m * ld + col0 + c] = c == lab ? 1.f : 0.f;
+}
+
+// --clip preprocessing (src/mlp_df_wgan_train.py:82-91) on the float64 feature matrix, in place
+__global__ void clip_bursts_kernel(double* __restrict__ X, long N, int S, double max_len, double max_out, double max_in) {
+    const long total = N * S;
+    for (long o = (long)blockIdx.x * blockDim.x + threadIdx.x; o < total; o += (long)gridDim.x * blockDim.x) {
+        const int j = (int)(o % S);
+        const double cap = j == 0 ? max_len : ((j & 1) ? max_out : max_in);
+        const double v = X[o];
+        if (v > cap) X[o] = cap;
+    }
+}
+
+// Sampler epilogue for one generated row y (fp32, tail already zeroed by the length mask):
+//   x = float(double(y) - min_)  ;  x = float(double(x) / scale_)      MinMaxScaler.inverse_transform on fp32
+//   lo/hi = first/last non-zero of x (np.trim_zeros, both ends); out = rint(x[lo..hi]) as int, 0 -> 1
+// out row is zero-filled past the length.  One workgroup per row.
+__global__ void sample_post_kernel(const float* __restrict__ Y, int ldy, int S, const double* __restrict__ min_,
+                                   const double* __restrict__ scale_, int* __restrict__ out, int ldo,
+                                   int* __restrict__ len_out) {
+    extern __shared__ float xs[];
+    __shared__ int s_lo, s_hi;
+    const int m = blockIdx.x;
+    if (threadIdx.x == 0) { s_lo = S; s_hi = -1; }
+    __syncthreads();
+    int lo = S, hi = -1;
+    for (int j = threadIdx.x; j < S; j += blockDim.x) {
+        float x = (float)((double)Y[(long)m * ldy + j] - min_[j]);
+        x = (float)((double)x / scale_[j]);
+        xs[j] = x;
+        if (x != 0.f) { lo = min(lo, j); hi = max(hi, j); }
+    }
+    atomicMin(&s_lo, lo);
+    atomicMax(&s_hi, hi);
+    __syncthreads();
+    lo = s_lo; hi = s_hi;
+    const int n = hi >= lo ? hi - lo + 1 : 0;
+    for (int j = threadIdx.x; j < S; j += blockDim.x) {
+        int v = 0;
+        if (j < n) {
+            v = (int)rintf(xs[lo + j]);
+            if (v == 0) v = 1;
+        }
+        out[(long)m * ldo + j] = v;
+    }
+    if (threadIdx.x == 0) len_out[m] = n;
+}
+
+}  // namespace
+
+extern "C" {
+
+int wfd_rng_dropout_mask(float* out, long n, float p, unsigned long long seed, unsigned long long offset,
+                         void* stream) {
+    if (!out || n <= 0 || p < 0.f || p >= 1.f) return WFD_ERR_ARG;
+    long blocks = (n / 4 + 255) / 256;
+    if (blocks > 2048) blocks = 2048;
+    if (blocks < 1) blocks = 1;
+    hipLaunchKernelGGL(rng_dropout_mask_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, out, n, p,
+                       seed, offset);
+    WFD_CHECK_LAUNCH();
+    return WFD_OK;
+}
+
+int wfd_rng_normal_rows(float* out, int ld, int M, int Z, unsigned long long seed, unsigned long long offset,
+                        void* stream) {
+    if (!out || M <= 0 || Z <= 0 || ld < Z) return WFD_ERR_ARG;
+    long blocks = (((long)M * Z + 3) / 4 + 255) / 256;
+    if (blocks > 2048) blocks = 2048;
+    hipLaunchKernelGGL(rng_normal_rows_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, out, ld, M, Z,
+                       seed, offset);
+    WFD_CHECK_LAUNCH();
+    return WFD_OK;
+}
+
+int wfd_gather_batch(const float* X, int ldX, const int* y, const long long* idx, int B, int S, int C, float* real,
+                     float* fake, int ldd, float* zin, int ldz, int Z, int* labels_out, void* stream) {
+    if (!X || !y || !idx || !real || B <= 0) return WFD_ERR_ARG;
+    hipLaunchKernelGGL(gather_batch_kernel, dim3(B), dim3(256), 0, (hipStream_t)stream, X, ldX, y, idx, S, C, real, fake,
+                       ldd, zin, ldz, Z, labels_out);
+    WFD_CHECK_LAUNCH();
+    return WFD_OK;
+}
+
+int wfd_onehot_rows(const int* labels, int M, int C, float* out, int ld, int col0, void* stream) {
+    if (!labels || !out || M <= 0) return WFD_ERR_ARG;
+    hipLaunchKernelGGL(onehot_rows_kernel, dim3(M), dim3(128), 0, (hipStream_t)stream, labels, M, C, out, ld, col0);
+    WFD_CHECK_LAUNCH();
+    return WFD_OK;
+}
+
+int wfd_clip_bursts(double* X, long N, int S, double max_len, double max_out, double max_in, void* stream) {
+    if (!X || N <= 0 || S <= 0) return WFD_ERR_ARG;
+    long blocks = (N * S + 255) / 256;
+    if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL(clip_bursts_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, X, N, S, max_len,
+                       max_out, max_in);
+    WFD_CHECK_LAUNCH();
+    return WFD_OK;
+}
+
+int wfd_sample_post(const float* Y, int ldy, int M, int S, const double* min_, const double* scale_, int* out, int ldo,
+                    int* len_out, void* stream) {
+    if (!Y || !min_ || !scale_ || !out || !len_out || (size_t)S * 4 > 60000) return WFD_ERR_ARG;
+    hipLaunchKernelGGL(sample_post_kernel, dim3(M), dim3(256), (size_t)S * sizeof(float), (hipStream_t)stream, Y, ldy, S,
+                       min_, scale_, out, ldo, len_out);
+    WFD_CHECK_LAUNCH();
+    return WFD_OK;
+}
+
+int wfd_version(void) { return 1; }
+
+}  // extern "C"

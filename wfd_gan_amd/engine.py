@@ -1,0 +1,498 @@
+"""Training-step engine: the loop body of the reference trainer (src/mlp_df_wgan_train.py:182-275) as two launch
+plans (D-step, G-step) over preallocated HBM buffers, in closed form (no autograd graph).
+
+Closed form used (verified against autograd by the oracle tests):
+  forward      z_i = h_{i-1} W_i^T + b_i ; d_i = mask_i * (z_i > 0 ? 1 : .2) ; h_i = z_i o d_i ; v = h_3 w_4 + b_4
+  chain        delta_3 = w_4 o d_3 ; delta_2 = (delta_3 W_3) o d_2 ; delta_1 = (delta_2 W_2) o d_1 ; g = (delta_1 W_1)[:, :S]
+  penalty      n = ||g||^2 ; W-div: mean(n_r^3 + n_f^3) ; seed ghat = 6 n^2 g / B
+  t-chain      t_1 = (ghat W_1[:, :S]^T) o d_1 ; t_2 = (t_1 W_2^T) o d_2 ; t_3 = (t_2 W_3^T) o d_3
+  grads        dW_i = [delta_i ; dv o delta_i]^T [t_{i-1} ; h_{i-1}]  (t_0 = ghat, h_0 = [x|c]) ; db_i = sum dv o delta_i
+               dw_4 = sum t_3 + sum dv o h_3 ; dv = -1/B (real rows), +1/B (fake rows)
+Real and fake rows are stacked (2B rows) so every weight matrix is streamed once per pass.
+"""
+from __future__ import annotations
+
+import math
+from typing import Dict, List, Optional, Sequence, Tuple
+
+import torch
+
+from ._lib import lib
+from .plan import (ACT_ELU, ACT_NONE, ACT_RELU, DM_ELU, DM_MUL, DM_NONE, DM_RELU, NN, NT, TN, Plan, Slabs, ptr, rup)
+
+G_PARAM_SPECS = lambda S, C, Z: [  # nn.Module.parameters() order of Generator, src/model.py:27-34
+    ("model.0.weight", (512, Z + C)), ("model.0.bias", (512,)),
+    ("model.2.weight", (1024, 512)), ("model.2.bias", (1024,)),
+    ("model.3.weight", (1024,)), ("model.3.bias", (1024,)),
+    ("model.5.weight", (2048, 1024)), ("model.5.bias", (2048,)),
+    ("model.6.weight", (2048,)), ("model.6.bias", (2048,)),
+    ("model.8.weight", (S, 2048)), ("model.8.bias", (S,)),
+]
+D_PARAM_SPECS = lambda S, C: [  # Discriminator, src/model.py:56-67
+    ("model.0.weight", (2048, S + C)), ("model.0.bias", (2048,)),
+    ("model.3.weight", (1024, 2048)), ("model.3.bias", (1024,)),
+    ("model.6.weight", (512, 1024)), ("model.6.bias", (512,)),
+    ("model.9.weight", (1, 512)), ("model.9.bias", (1,)),
+]
+G_BUFFER_KEYS = ["model.3.running_mean", "model.3.running_var", "model.6.running_mean", "model.6.running_var"]
+
+DF_CONVS = [  # (conv prefix, bn prefix, Cin, Cout, act, pool_after) -- src/model.py:140-185
+    ("layer1.0", "layer1.1", 1, 32, ACT_ELU, False), ("layer1.3", "layer1.4", 32, 32, ACT_ELU, True),
+    ("layer2.0", "layer2.1", 32, 64, ACT_RELU, False), ("layer2.3", "layer2.4", 64, 64, ACT_RELU, True),
+    ("layer3.0", "layer3.1", 64, 128, ACT_RELU, False), ("layer3.3", "layer3.4", 128, 128, ACT_RELU, True),
+    ("layer4.0", "layer4.1", 128, 256, ACT_RELU, True),
+]
+
+
+class FlatParams:
+    """Parameters of one network in ONE flat fp32 buffer (tensor offsets 16-byte aligned) with matching flat
+    gradient and RMSprop square-average buffers: the optimizer and the gradient all-reduce are one pass each."""
+
+    def __init__(self, specs, device):
+        self.specs = specs
+        self.offsets: Dict[str, int] = {}
+        off = 0
+        for name, shape in specs:
+            self.offsets[name] = off
+            off += rup(math.prod(shape), 4)
+        self.numel = off
+        self.flat = torch.zeros(off, dtype=torch.float32, device=device)
+        self.grad = torch.zeros(off, dtype=torch.float32, device=device)
+        self.sq = torch.zeros(off, dtype=torch.float32, device=device)
+        self.p = {n: self.flat[self.offsets[n]: self.offsets[n] + math.prod(s)].view(s) for n, s in specs}
+        self.g = {n: self.grad[self.offsets[n]: self.offsets[n] + math.prod(s)].view(s) for n, s in specs}
+
+    def load(self, sd: Dict[str, torch.Tensor]):
+        for n, s in self.specs:
+            t = sd[n]
+            if tuple(t.shape) != tuple(s):
+                raise RuntimeError(f"size mismatch for {n}: expected {tuple(s)}, got {tuple(t.shape)}")
+            self.p[n].copy_(t.detach().to(torch.float32))
+
+    def state(self) -> Dict[str, torch.Tensor]:
+        return {n: self.p[n].detach().clone() for n, _ in self.specs}
+
+
+def fold_bn(sd, bn: str, lin_bias: torch.Tensor, eps: float = 1e-5):
+    """eval-mode BatchNorm after a conv / linear with bias -> per-channel (scale, shift)."""
+    scale = sd[f"{bn}.weight"].double() / torch.sqrt(sd[f"{bn}.running_var"].double() + eps)
+    shift = (lin_bias.double() - sd[f"{bn}.running_mean"].double()) * scale + sd[f"{bn}.bias"].double()
+    return scale.float().contiguous(), shift.float().contiguous()
+
+
+class ObserverDF:
+    """Frozen DF observer (src/model.py:135-212, eval mode) packed for the channels-last kernels: conv weights as
+    [Cout][8*Cin] (tap-major), their tap-flipped transposes for the input gradient, BN folded to scale/shift."""
+
+    def __init__(self, sd: Dict[str, torch.Tensor], length: int, num_classes: int, device):
+        sd = {k: v.detach().to(device=device) for k, v in sd.items()}
+        self.L = length
+        self.C = num_classes
+        self.Ls = [length]
+        for _ in range(4):
+            self.Ls.append((self.Ls[-1] + 7) // 8)
+        self.convs = []
+        for conv, bn, cin, cout, act, pool in DF_CONVS:
+            w = sd[f"{conv}.conv.weight"].float()
+            assert tuple(w.shape) == (cout, cin, 8), (conv, tuple(w.shape))
+            scale, shift = fold_bn(sd, bn, sd[f"{conv}.conv.bias"])
+            fwd = w.permute(0, 2, 1).reshape(cout, 8 * cin).contiguous()
+            bwd = w.flip(2).permute(1, 2, 0).reshape(cin, 8 * cout).contiguous()
+            self.convs.append(dict(cin=cin, cout=cout, act=act, pool=pool, w=fwd, wT=bwd, scale=scale, shift=shift,
+                                   w_raw=w.reshape(cout, cin * 8).contiguous()))
+        L4 = self.Ls[4]
+        w1 = sd["layer5.0.weight"].float()
+        assert tuple(w1.shape) == (512, 256 * L4), tuple(w1.shape)
+        self.fc1_w = w1.view(512, 256, L4).permute(0, 2, 1).reshape(512, L4 * 256).contiguous()
+        self.fc1_scale, self.fc1_shift = fold_bn(sd, "layer5.1", sd["layer5.0.bias"])
+        self.fc2_w = sd["layer5.4.weight"].float().contiguous()
+        self.fc2_scale, self.fc2_shift = fold_bn(sd, "layer5.5", sd["layer5.4.bias"])
+        self.fc_w = sd["fc.weight"].float().contiguous()
+        self.fc_b = sd["fc.bias"].float().contiguous()
+        assert tuple(self.fc_w.shape) == (num_classes, 512)
+
+
+class TrainEngine:
+    """One rank's state for the training hot path.  ``B`` is the per-rank batch (rows per side)."""
+
+    def __init__(self, seq_len: int, class_dim: int, latent_dim: int, batch: int, scaler_min: float,
+                 scaler_max: float, G_state: Dict[str, torch.Tensor], D_state: Dict[str, torch.Tensor],
+                 DF_state: Dict[str, torch.Tensor], lr: float = 2e-4, alpha: float = 0.02, n_critic: int = 3,
+                 penalty: str = "div", lambda_gp: float = 10.0, device="cuda:0", global_batch: Optional[int] = None,
+                 seed: int = 0, workspace_mb: int = 256):
+        if not torch.cuda.is_available():
+            raise RuntimeError("wfd_gan_amd.TrainEngine needs a HIP device: there is no CPU path")
+        if penalty not in ("div", "gp"):
+            raise ValueError("penalty must be 'div' (what the reference runs) or 'gp' (src/utils.py:64-84)")
+        self.L = lib()
+        self.dev = torch.device(device)
+        S, C, Z, B = seq_len, class_dim, latent_dim, batch
+        self.S, self.C, self.Z, self.B = S, C, Z, B
+        self.Bg = global_batch or B              # global batch: means are over all ranks' rows
+        self.lr, self.alpha, self.n_critic = lr, alpha, n_critic
+        self.penalty, self.lambda_gp = penalty, lambda_gp
+        # python floats -> the fp32 constants torch would use for `tensor * scalar`
+        self.range_f = float(scaler_max - scaler_min)
+        self.smin_f = float(scaler_min)
+        self.scaler_min, self.scaler_max = scaler_min, scaler_max
+        self.seed = seed
+        self.rng_offset = 0
+        self.nbt = {"model.3": 0, "model.6": 0}
+        dev = self.dev
+        f32 = dict(dtype=torch.float32, device=dev)
+
+        self.Gp = FlatParams(G_PARAM_SPECS(S, C, Z), dev)
+        self.Dp = FlatParams(D_PARAM_SPECS(S, C), dev)
+        self.Gp.load(G_state)
+        self.Dp.load(D_state)
+        self.Gbuf = {k: G_state[k].detach().to(**f32).clone() for k in G_BUFFER_KEYS}
+        for k in self.nbt:
+            if f"{k}.num_batches_tracked" in G_state:
+                self.nbt[k] = int(G_state[f"{k}.num_batches_tracked"])
+        self.df = ObserverDF(DF_state, S - 1, C, dev)
+
+        # ---- activations -------------------------------------------------------------------------------
+        self.nside = 2 if penalty == "div" else 3     # row groups per D-step: real, fake (, interpolates)
+        M = self.nside * B
+        self.M = M
+        ldx, ldz = rup(S + C, 4), rup(Z + C, 4)
+        self.ldx, self.ldz = ldx, ldz
+        z = lambda *s: torch.zeros(*s, **f32)
+        b = self.buf = {}
+        b["XC"] = z(2 * M, ldx)          # rows [0,M): penalty seeds ghat ; rows [M,2M): D inputs [x|c]
+        b["ZIN"] = z(B, ldz)             # generator input [z|c]
+        b["labels"] = torch.zeros(B, dtype=torch.int32, device=dev)
+        for i, n in ((1, 2048), (2, 1024), (3, 512)):
+            b[f"MK{i}"] = z(M, n)        # dropout keep-masks {0,1.25}
+            b[f"D{i}"] = z(M, n)         # local derivatives d_i
+            b[f"DL{i}"] = z(2 * M, n)    # [delta_i ; dv o delta_i]
+        b["T1H1"] = z(2 * M, 2048)       # [t_1 ; h_1]
+        b["T2H2"] = z(2 * M, 1024)       # [t_2 ; h_2]
+        b["H3"], b["T3"] = z(M, 512), z(M, 512)
+        b["V"], b["NSQ"], b["PEN"], b["DV"], b["PENFLAG"] = z(M), z(M), z(M), z(M), z(M)
+        b["dstats"], b["dacc"] = z(8), z(4)
+        b["gstats"], b["gacc"], b["ghead"] = z(8), z(4), z(2)
+        # generator
+        b["GH1"] = z(B, 512)
+        for i, n in ((2, 1024), (3, 2048)):
+            b[f"GZ{i}"], b[f"GXH{i}"], b[f"GH{i}"] = z(B, n), z(B, n), z(B, n)
+            b[f"mean{i}"], b[f"m2{i}"], b[f"istd{i}"], b[f"bns{i}"] = z(n), z(n), z(n), z(2 * n)
+            b[f"GDZ{i}"] = z(B, n)
+        b["GDZ1"] = z(B, 512)
+        self.lds4 = rup(S, 4)
+        b["GDZ4"] = z(B, self.lds4)
+        b["idx"] = torch.zeros(B, dtype=torch.int32, device=dev)
+        b["err"] = torch.zeros(1, dtype=torch.int32, device=dev)
+        # G-step critic pass (fake rows only)
+        for i, n in ((1, 2048), (2, 1024), (3, 512)):
+            b[f"gMK{i}"], b[f"gD{i}"], b[f"gDL{i}"] = z(B, n), z(B, n), z(B, n)
+        b["gH1"], b["gH2"], b["gH3"], b["gV"] = z(B, 2048), z(B, 1024), z(B, 512), z(B)
+        # observer
+        df = self.df
+        Ls = df.Ls
+        b["Y"] = [z(B * Ls[0], 32), z(B * Ls[0], 32), z(B * Ls[1], 64), z(B * Ls[1], 64), z(B * Ls[2], 128),
+                  z(B * Ls[2], 128), z(B * Ls[3], 256)]
+        b["PO"] = [z(B * Ls[1], 32), z(B * Ls[2], 64), z(B * Ls[3], 128), z(B * Ls[4], 256)]
+        b["DC"] = [torch.zeros_like(t) for t in b["Y"]]
+        b["DPO"] = [torch.zeros_like(t) for t in b["PO"]]
+        b["F1"], b["F2"], b["DF1"], b["DF2"] = z(B, 512), z(B, 512), z(B, 512), z(B, 512)
+        self.ldc = rup(C, 4)
+        b["LOG"], b["DLOG"], b["CE"] = z(B, self.ldc), z(B, self.ldc), z(B)
+        self.ldl = rup(S - 1, 4)
+        b["DDF"] = z(B, self.ldl)
+        b["ws"] = torch.empty(workspace_mb * (1 << 18), **f32)
+
+        self._fill_row_constants()
+        self.plan_d = self._build_d_plan()
+        self.plan_g = self._build_g_plan()
+        self.graph_d = self.graph_g = None
+
+    # ------------------------------------------------------------------------------------------------------
+    @property
+    def din(self):
+        return self.buf["XC"][self.M:]
+
+    @property
+    def real_rows(self):
+        return self.din[: self.B]
+
+    @property
+    def fake_rows(self):
+        return self.din[self.B: 2 * self.B]
+
+    def _fill_row_constants(self):
+        B, b = self.B, self.buf
+        dv = torch.zeros(self.M)
+        dv[:B] = -1.0 / self.Bg
+        dv[B:2 * B] = 1.0 / self.Bg
+        flag = torch.zeros(self.M)
+        if self.penalty == "div":
+            flag[:] = 1.0
+        else:
+            flag[2 * B:] = 1.0
+        b["DV"].copy_(dv)
+        b["PENFLAG"].copy_(flag)
+
+    # ------------------------------------------------------------------------------------------------------
+    def _g_forward(self, p: Plan, nupd: int):
+        """Generator.forward in training mode (src/model.py:36-48) -> fake rows of the critic input."""
+        B, S, C, Z, b, G = self.B, self.S, self.C, self.Z, self.buf, self.Gp.p
+        s = p.gemm(NT, b["ZIN"], self.ldz, G["model.0.weight"], Z + C, B, 512, Z + C)
+        p.affine_act(s, None, G["model.0.bias"], ACT_RELU, b["GH1"], 512)
+        prev, kprev = b["GH1"], 512
+        for i, lin, bn, n in ((2, "model.2", "model.3", 1024), (3, "model.5", "model.6", 2048)):
+            s = p.gemm(NT, prev, kprev, G[f"{lin}.weight"], kprev, B, n, kprev)
+            p.add(self.L.bn_stats, s.ptr, s.ns, s.ss, s.ldp, B, n, ptr(G[f"{lin}.bias"]), ptr(b[f"GZ{i}"]), n,
+                  ptr(b[f"mean{i}"]), ptr(b[f"m2{i}"]))
+            self._bn_sync_hook(p, i)
+            p.add(self.L.bn_apply_relu, ptr(b[f"GZ{i}"]), n, B, n, ptr(b[f"mean{i}"]), ptr(b[f"m2{i}"]),
+                  float(self.Bg), 0.8, ptr(G[f"{bn}.weight"]), ptr(G[f"{bn}.bias"]), ptr(b[f"GXH{i}"]),
+                  ptr(b[f"GH{i}"]), n, ptr(b[f"istd{i}"]), ptr(self.Gbuf[f"{bn}.running_mean"]),
+                  ptr(self.Gbuf[f"{bn}.running_var"]), 0.1, nupd)
+            prev, kprev = b[f"GH{i}"], n
+        s = p.gemm(NT, prev, 2048, G["model.8.weight"], 2048, B, S, 2048)
+        p.add(self.L.ep_sigmoid_lenmask, s.ptr, s.ns, s.ss, s.ldp, B, S, ptr(G["model.8.bias"]), self.range_f,
+              self.smin_f, ptr(self.fake_rows), self.ldx, ptr(b["idx"]), ptr(b["err"]))
+
+    def _bn_sync_hook(self, p: Plan, layer: int):
+        """data-parallel: (mean, M2) of all ranks are combined here (parallel.py); single rank: nothing."""
+        return
+
+    def _critic_forward(self, p: Plan, X, M: int, mk, H1, H2, H3, D1, D2, D3, V, DL3, DL3s, rowscale):
+        """Discriminator.forward (src/model.py:69-72) on M rows of X, keeping d_i; ends with the head + delta_3."""
+        S, C, D = self.S, self.C, self.Dp.p
+        s = p.gemm(NT, X, self.ldx, D["model.0.weight"], S + C, M, 2048, S + C)
+        p.lrelu_drop(s, D["model.0.bias"], mk[0], 2048, H1, 2048, D1, 2048)
+        s = p.gemm(NT, H1, 2048, D["model.3.weight"], 2048, M, 1024, 2048)
+        p.lrelu_drop(s, D["model.3.bias"], mk[1], 1024, H2, 1024, D2, 1024)
+        s = p.gemm(NT, H2, 1024, D["model.6.weight"], 1024, M, 512, 1024)
+        p.lrelu_drop(s, D["model.6.bias"], mk[2], 512, H3, 512, D3, 512)
+        p.add(self.L.d_head, ptr(H3), 512, ptr(D3), 512, ptr(D["model.9.weight"]), ptr(D["model.9.bias"]), M, 512,
+              ptr(rowscale), ptr(V), ptr(DL3), ptr(DL3s), 512)
+
+    def _critic_chain(self, p: Plan, M: int, DL3, DL2, DL2s, DL1, DL1s, D2, D1, rowscale) -> Slabs:
+        """d validity / d traces in closed form; returns the slabs of g = (delta_1 W_1)[:, :S]."""
+        S, C, D = self.S, self.C, self.Dp.p
+        s = p.gemm(NN, DL3, 512, D["model.6.weight"], 1024, M, 1024, 512)
+        p.mul(s, D2, 1024, DM_MUL, None, rowscale, DL2, DL2s, 1024)
+        s = p.gemm(NN, DL2, 1024, D["model.3.weight"], 2048, M, 2048, 1024)
+        p.mul(s, D1, 2048, DM_MUL, None, rowscale, DL1, DL1s, 2048)
+        return p.gemm(NN, DL1, 2048, D["model.0.weight"], S + C, M, S, 2048)
+
+    def _build_d_plan(self) -> Plan:
+        B, M, S, C, b, D = self.B, self.M, self.S, self.C, self.buf, self.Dp
+        p = Plan(b["ws"])
+        self._g_forward(p, nupd=1)
+        if self.penalty == "gp":
+            raise NotImplementedError  # filled in by _gp_interpolate below when enabled
+        din = self.din
+        H1, H2 = b["T1H1"][M:], b["T2H2"][M:]
+        self._critic_forward(p, din, M, (b["MK1"], b["MK2"], b["MK3"]), H1, H2, b["H3"], b["D1"], b["D2"], b["D3"],
+                             b["V"], b["DL3"][:M], b["DL3"][M:], b["DV"])
+        g = self._critic_chain(p, M, b["DL3"][:M], b["DL2"][:M], b["DL2"][M:], b["DL1"][:M], b["DL1"][M:], b["D2"],
+                               b["D1"], b["DV"])
+        mode = 0 if self.penalty == "div" else 1
+        p.add(self.L.ep_penalty_row, g.ptr, g.ns, g.ss, g.ldp, M, S, mode, 1.0 / self.Bg, self.lambda_gp,
+              ptr(b["NSQ"]), ptr(b["PEN"]), ptr(b["XC"]), self.ldx)
+        p.add(self.L.d_loss, ptr(b["V"]), ptr(b["PEN"]), B, M, 1.0 / self.Bg, 1.0, ptr(b["dstats"]), ptr(b["dacc"]))
+        # t-chain (second-order part of d_loss.backward())
+        Dp = D.p
+        s = p.gemm(NT, b["XC"], self.ldx, Dp["model.0.weight"], S + C, M, 2048, S)
+        p.mul(s, b["D1"], 2048, DM_MUL, None, None, b["T1H1"][:M], None, 2048)
+        s = p.gemm(NT, b["T1H1"][:M], 2048, Dp["model.3.weight"], 2048, M, 1024, 2048)
+        p.mul(s, b["D2"], 1024, DM_MUL, None, None, b["T2H2"][:M], None, 1024)
+        s = p.gemm(NT, b["T2H2"][:M], 1024, Dp["model.6.weight"], 1024, M, 512, 1024)
+        p.mul(s, b["D3"], 512, DM_MUL, None, None, b["T3"], None, 512)
+        # weight gradients: one TN product per layer over the stacked [penalty ; standard] rows
+        p.gemm(TN, b["DL1"], 2048, b["XC"], self.ldx, 2048, S + C, 2 * M, out=D.g["model.0.weight"], ldp=S + C)
+        p.gemm(TN, b["DL2"], 1024, b["T1H1"], 2048, 1024, 2048, 2 * M, out=D.g["model.3.weight"], ldp=2048)
+        p.gemm(TN, b["DL3"], 512, b["T2H2"], 1024, 512, 1024, 2 * M, out=D.g["model.6.weight"], ldp=1024)
+        p.add(self.L.colsum, ptr(b["DL1"][M:]), 2048, M, 2048, 0, ptr(D.g["model.0.bias"]), 0)
+        p.add(self.L.colsum, ptr(b["DL2"][M:]), 1024, M, 1024, 0, ptr(D.g["model.3.bias"]), 0)
+        p.add(self.L.colsum, ptr(b["DL3"][M:]), 512, M, 512, 0, ptr(D.g["model.6.bias"]), 0)
+        p.add(self.L.colsum, ptr(b["T3"]), 512, M, 512, 0, ptr(D.g["model.9.weight"]), 0)
+        p.add(self.L.colsum, ptr(b["H3"]), 512, M, 512, ptr(b["DV"]), ptr(D.g["model.9.weight"]), 1)
+        p.add(self.L.colsum, ptr(b["DV"]), 1, M, 1, 0, ptr(D.g["model.9.bias"]), 0)
+        self._grad_sync_hook(p, "D")
+        p.add(self.L.rmsprop, ptr(D.flat), ptr(D.grad), ptr(D.sq), D.numel, self.lr, 0.99, 1e-8, 1.0)
+        return p
+
+    def _grad_sync_hook(self, p: Plan, which: str):
+        return
+
+    def _observer(self, p: Plan):
+        """DF forward on fake[:, 1:], masked CE, and the input gradient dDF (src/mlp_df_wgan_train.py:251-263,273)."""
+        B, b, df = self.B, self.buf, self.df
+        Ls, Y, PO, DC, DPO = df.Ls, b["Y"], b["PO"], b["DC"], b["DPO"]
+        cv = df.convs
+        # ---- forward
+        p.add(self.L.df_conv1_fwd, ptr(self.fake_rows), self.ldx, 1, B, Ls[0], ptr(cv[0]["w_raw"]),
+              ptr(cv[0]["scale"]), ptr(cv[0]["shift"]), cv[0]["act"], ptr(Y[0]), 32)
+        cur, lvl, pi = Y[0], 0, 0
+        for k in range(1, 7):
+            c = cv[k]
+            s = p.conv8(cur, B, Ls[lvl], c["cin"], 3, c["w"], c["cout"])
+            p.affine_act(s, c["scale"], c["shift"], c["act"], Y[k], c["cout"])
+            cur = Y[k]
+            if c["pool"]:
+                p.add(self.L.df_pool8_fwd, ptr(cur), B, Ls[lvl], c["cout"], ptr(PO[pi]))
+                cur, lvl, pi = PO[pi], lvl + 1, pi + 1
+        kin = 256 * Ls[4]
+        s = p.gemm(NT, PO[3], kin, df.fc1_w, kin, B, 512, kin)
+        p.affine_act(s, df.fc1_scale, df.fc1_shift, ACT_RELU, b["F1"], 512)
+        s = p.gemm(NT, b["F1"], 512, df.fc2_w, 512, B, 512, 512)
+        p.affine_act(s, df.fc2_scale, df.fc2_shift, ACT_RELU, b["F2"], 512)
+        s = p.gemm(NT, b["F2"], 512, df.fc_w, 512, B, self.C, 512)
+        p.affine_act(s, None, df.fc_b, ACT_NONE, b["LOG"], self.ldc)
+        self._nsel_sync_hook(p)
+        p.add(self.L.masked_ce, ptr(b["LOG"]), self.ldc, B, self.C, ptr(b["labels"]), ptr(b["gV"]),
+              b["ghead"].data_ptr() + 4, self.alpha, ptr(b["CE"]), ptr(b["DLOG"]), self.ldc)
+        p.add(self.L.g_loss, ptr(b["CE"]), B, ptr(b["ghead"]), self.alpha, ptr(b["gstats"]), ptr(b["gacc"]))
+        # ---- input gradient
+        s = p.gemm(NN, b["DLOG"], self.ldc, df.fc_w, 512, B, 512, self.C)
+        p.mul(s, b["F2"], 512, DM_RELU, df.fc2_scale, None, b["DF2"], None, 512)
+        s = p.gemm(NN, b["DF2"], 512, df.fc2_w, 512, B, 512, 512)
+        p.mul(s, b["F1"], 512, DM_RELU, df.fc1_scale, None, b["DF1"], None, 512)
+        s = p.gemm(NN, b["DF1"], 512, df.fc1_w, kin, B, kin, 512)
+        p.mul(s, None, 0, DM_NONE, None, None, DPO[3], None, kin)
+        # walk the conv stack backwards; `lvl` = index of the length the conv runs at
+        k, lvl, pi = 6, 3, 3
+        while k >= 1:
+            c = cv[k]
+            if c["pool"]:
+                p.add(self.L.df_pool8_bwd_act, ptr(DPO[pi]), ptr(Y[k]), B, Ls[lvl], c["cout"], ptr(c["scale"]),
+                      c["act"], ptr(DC[k]))
+                pi -= 1
+            # DC[k] = gradient at conv k's raw output.  Push it through conv k to the activation feeding it.
+            s = p.conv8(DC[k], B, Ls[lvl], c["cout"], 4, c["wT"], c["cin"])
+            prev = cv[k - 1]
+            if prev["pool"]:
+                p.mul(s, None, 0, DM_NONE, None, None, DPO[pi], None, c["cin"])
+                lvl -= 1
+            else:
+                dm = DM_ELU if prev["act"] == ACT_ELU else DM_RELU
+                p.mul(s, Y[k - 1], prev["cout"], dm, prev["scale"], None, DC[k - 1], None, prev["cout"])
+            k -= 1
+        p.add(self.L.df_conv1_bwd, ptr(DC[0]), B, Ls[0], 32, ptr(cv[0]["w_raw"]), ptr(b["DDF"]), self.ldl)
+
+    def _nsel_sync_hook(self, p: Plan):
+        return
+
+    def _build_g_plan(self) -> Plan:
+        B, S, C, Z, b, G = self.B, self.S, self.C, self.Z, self.buf, self.Gp
+        p = Plan(b["ws"])
+        # The generator parameters and z are unchanged since the D-step's forward, so the second
+        # generator(z, c) of :240 reproduces the same activations; only its BN running-stat update is new.
+        for i, bn, n in ((2, "model.3", 1024), (3, "model.6", 2048)):
+            p.add(self.L.bn_running_update, ptr(b[f"mean{i}"]), ptr(b[f"m2{i}"]), float(self.Bg), n,
+                  ptr(self.Gbuf[f"{bn}.running_mean"]), ptr(self.Gbuf[f"{bn}.running_var"]), 0.1, 1)
+        self._critic_forward(p, self.fake_rows, B, (b["gMK1"], b["gMK2"], b["gMK3"]), b["gH1"], b["gH2"], b["gH3"],
+                             b["gD1"], b["gD2"], b["gD3"], b["gV"], b["gDL3"], None, None)
+        p.add(self.L.g_head, ptr(b["gV"]), B, 1.0 / self.Bg, ptr(b["ghead"]))
+        self._observer(p)
+        g = self._critic_chain(p, B, b["gDL3"], b["gDL2"], None, b["gDL1"], None, b["gD2"], b["gD1"], None)
+        p.add(self.L.g_out_bwd, g.ptr, g.ns, g.ss, g.ldp, B, S, -1.0 / self.Bg, ptr(b["DDF"]), self.ldl,
+              ptr(self.fake_rows), self.ldx, ptr(b["idx"]), ptr(b["GDZ4"]), self.lds4, ptr(G.g["model.8.bias"]))
+        # generator backward
+        Gp = G.p
+        p.gemm(TN, b["GDZ4"], self.lds4, b["GH3"], 2048, S, 2048, B, out=G.g["model.8.weight"], ldp=2048)
+        prev_dz, kdz, wkey = b["GDZ4"], S, "model.8.weight"
+        lddz = self.lds4
+        for i, lin, bn, n, hin, kin in ((3, "model.5", "model.6", 2048, b["GH2"], 1024),
+                                        (2, "model.2", "model.3", 1024, b["GH1"], 512)):
+            s = p.gemm(NN, prev_dz, lddz, Gp[wkey], n, B, n, kdz)
+            self._bn_bwd(p, s, i, lin, bn, n)
+            p.gemm(TN, b[f"GDZ{i}"], n, hin, kin, n, kin, B, out=G.g[f"{lin}.weight"], ldp=kin)
+            prev_dz, kdz, wkey, lddz = b[f"GDZ{i}"], n, f"{lin}.weight", n
+        s = p.gemm(NN, prev_dz, 1024, Gp["model.2.weight"], 512, B, 512, 1024)
+        p.mul(s, b["GH1"], 512, DM_RELU, None, None, b["GDZ1"], None, 512)
+        p.add(self.L.colsum, ptr(b["GDZ1"]), 512, B, 512, 0, ptr(G.g["model.0.bias"]), 0)
+        p.gemm(TN, b["GDZ1"], 512, b["ZIN"], self.ldz, 512, Z + C, B, out=G.g["model.0.weight"], ldp=Z + C)
+        self._grad_sync_hook(p, "G")
+        p.add(self.L.rmsprop, ptr(G.flat), ptr(G.grad), ptr(G.sq), G.numel, self.lr, 0.99, 1e-8, 1.0)
+        return p
+
+    def _bn_bwd(self, p: Plan, s: Slabs, i: int, lin: str, bn: str, n: int):
+        b, G = self.buf, self.Gp
+        p.add(self.L.bn_bwd, s.ptr, s.ns, s.ss, s.ldp, self.B, n, ptr(b[f"GH{i}"]), ptr(b[f"GXH{i}"]), n,
+              ptr(G.p[f"{bn}.weight"]), ptr(b[f"istd{i}"]), float(self.Bg), ptr(b[f"bns{i}"]), ptr(b[f"GDZ{i}"]), n,
+              ptr(G.g[f"{bn}.weight"]), ptr(G.g[f"{bn}.bias"]), ptr(G.g[f"{lin}.bias"]), 3)
+
+    # ------------------------------------------------------------------------------------------------------
+    # inputs
+    def set_batch(self, traces: torch.Tensor, labels: torch.Tensor, z: torch.Tensor):
+        """Explicit batch (parity mode): traces (B,S) scaled features, labels (B,) ints, z (B,Z)."""
+        B, S, C, Z, b = self.B, self.S, self.C, self.Z, self.buf
+        labels = labels.to(self.dev)
+        onehot = torch.zeros(B, C, dtype=torch.float32, device=self.dev)
+        onehot[torch.arange(B, device=self.dev), labels.long()] = 1.0
+        self.real_rows[:, :S].copy_(traces.to(self.dev, torch.float32))
+        self.real_rows[:, S:S + C].copy_(onehot)
+        self.fake_rows[:, S:S + C].copy_(onehot)
+        b["ZIN"][:, :Z].copy_(z.to(self.dev, torch.float32))
+        b["ZIN"][:, Z:Z + C].copy_(onehot)
+        b["labels"].copy_(labels.to(torch.int32))
+
+    def set_masks(self, d_masks: Optional[Sequence[torch.Tensor]] = None,
+                  g_masks: Optional[Sequence[torch.Tensor]] = None):
+        """Explicit dropout keep-masks (values {0, 1.25}).  d_masks: 3 tensors of M rows (real rows first, then
+        fake); g_masks: 3 tensors of B rows for the G-step's critic pass."""
+        if d_masks is not None:
+            for i, m in enumerate(d_masks):
+                self.buf[f"MK{i + 1}"].copy_(m.to(self.dev, torch.float32))
+        if g_masks is not None:
+            for i, m in enumerate(g_masks):
+                self.buf[f"gMK{i + 1}"].copy_(m.to(self.dev, torch.float32))
+
+    def draw_masks(self, g_step: bool):
+        """Fast mode: Philox keep-masks on device (one launch per mask tensor)."""
+        st = torch.cuda.current_stream().cuda_stream
+        names = ["MK1", "MK2", "MK3"] + (["gMK1", "gMK2", "gMK3"] if g_step else [])
+        for nme in names:
+            t = self.buf[nme]
+            self.L.rng_dropout_mask(t.data_ptr(), t.numel(), 0.2, self.seed, self.rng_offset, st)
+            self.rng_offset += (t.numel() + 3) // 4
+
+    def draw_z(self):
+        st = torch.cuda.current_stream().cuda_stream
+        self.L.rng_normal_rows(self.buf["ZIN"].data_ptr(), self.ldz, self.B, self.Z, self.seed ^ 0x5A5A5A5A,
+                               self.rng_offset, st)
+        self.rng_offset += (self.B * self.Z + 3) // 4
+
+    # ------------------------------------------------------------------------------------------------------
+    def d_step(self):
+        self.plan_d.run()
+        self.nbt["model.3"] += 1
+        self.nbt["model.6"] += 1
+
+    def g_step(self):
+        self.plan_g.run()
+        self.nbt["model.3"] += 1
+        self.nbt["model.6"] += 1
+
+    def check_length_index(self):
+        """Host sync: raise what the reference raises when the sigmoid saturates (src/model.py:44)."""
+        if int(self.buf["err"].item()) != 0:
+            raise IndexError("index out of bounds in the generator's burst-length mask (model.py:44 semantics)")
+
+    def d_stats(self) -> Dict[str, float]:
+        v = self.buf["dstats"].tolist()
+        return dict(d_loss=v[0], penalty=v[1], w_dist=v[2], mean_rv=v[3], mean_fv=v[4])
+
+    def g_stats(self) -> Dict[str, float]:
+        v = self.buf["gstats"].tolist()
+        return dict(g_loss=v[0], f_loss=v[1], g_combined=v[2], n_sel=int(v[3]))
+
+    def generator_state(self) -> Dict[str, torch.Tensor]:
+        sd = {}
+        for key in ("model.0", "model.2", "model.3", "model.5", "model.6", "model.8"):
+            sd[f"{key}.weight"] = self.Gp.p[f"{key}.weight"].detach().clone()
+            sd[f"{key}.bias"] = self.Gp.p[f"{key}.bias"].detach().clone()
+            if key in ("model.3", "model.6"):
+                sd[f"{key}.running_mean"] = self.Gbuf[f"{key}.running_mean"].clone()
+                sd[f"{key}.running_var"] = self.Gbuf[f"{key}.running_var"].clone()
+                sd[f"{key}.num_batches_tracked"] = torch.tensor(self.nbt[key], dtype=torch.int64)
+        return sd
+
+    def discriminator_state(self) -> Dict[str, torch.Tensor]:
+        return self.Dp.state()

@@ -1,0 +1,97 @@
+"""Launch plans: a step of the hot path is a fixed list of C-ABI calls on preallocated device buffers.
+
+All pointers and sizes are resolved once when the plan is built; running a plan is a tight loop of ctypes calls
+that only appends the stream, so the same plan can be run eagerly or captured into a HIP graph
+(torch.cuda.CUDAGraph) and replayed with one launch.
+"""
+from __future__ import annotations
+
+from collections import namedtuple
+from typing import List, Optional, Tuple
+
+import torch
+
+from ._lib import lib
+
+Slabs = namedtuple("Slabs", "ptr ns ss ldp M N")
+
+NT, NN, TN = 0, 1, 2
+ACT_NONE, ACT_RELU, ACT_ELU, ACT_SIGMOID = 0, 1, 2, 3
+DM_NONE, DM_MUL, DM_RELU, DM_ELU = 0, 1, 2, 3
+
+
+def ptr(t) -> int:
+    if t is None:
+        return 0
+    if isinstance(t, int):
+        return t
+    return t.data_ptr()
+
+
+def rup(x: int, m: int) -> int:
+    return (x + m - 1) // m * m
+
+
+class Plan:
+    """Accumulates (function, args) pairs; ``run(stream)`` launches them in order."""
+
+    def __init__(self, workspace: torch.Tensor):
+        self.L = lib()
+        self.ws = workspace            # fp32 scratch for split-K slabs
+        self.ws_floats = workspace.numel()
+        self.calls: List[Tuple] = []
+        self.keep = []                 # tensors referenced by raw pointer
+
+    # -- generic ------------------------------------------------------------------------------------------
+    def add(self, fn, *args):
+        self.calls.append((fn, args))
+
+    def run(self, stream: Optional[int] = None):
+        if stream is None:
+            stream = torch.cuda.current_stream().cuda_stream
+        for fn, a in self.calls:
+            fn(*a, stream)
+
+    def __len__(self):
+        return len(self.calls)
+
+    # -- contractions -------------------------------------------------------------------------------------
+    def gemm(self, layout: int, A, lda: int, B, ldb: int, M: int, N: int, K: int, out=None, ldp: Optional[int] = None,
+             splits: Optional[int] = None) -> Slabs:
+        """Raw product into the slab workspace (or straight into ``out`` with splits = 1)."""
+        if out is not None:
+            self.add(self.L.gemm_f32, layout, ptr(A), lda, ptr(B), ldb, ptr(out), ldp, 0, M, N, K, 1)
+            return Slabs(ptr(out), 1, 0, ldp, M, N)
+        ldp = rup(N, 4)
+        ns = splits or self.L.gemm_pick_splits(M, N, K)
+        ss = M * ldp
+        while ns > 1 and ns * ss > self.ws_floats:
+            ns -= 1
+        if ns * ss > self.ws_floats:
+            raise RuntimeError(f"slab workspace too small: need {ns * ss} floats, have {self.ws_floats}")
+        self.add(self.L.gemm_f32, layout, ptr(A), lda, ptr(B), ldb, ptr(self.ws), ldp, ss, M, N, K, ns)
+        return Slabs(ptr(self.ws), ns, ss, ldp, M, N)
+
+    def conv8(self, X, Bn: int, L: int, Cin: int, pad: int, Wp, Cout: int) -> Slabs:
+        M, K = Bn * L, 8 * Cin
+        ldp = rup(Cout, 4)
+        ns = self.L.gemm_pick_splits(M, Cout, K)
+        ss = M * ldp
+        while ns > 1 and ns * ss > self.ws_floats:
+            ns -= 1
+        if ns * ss > self.ws_floats:
+            raise RuntimeError("slab workspace too small for conv")
+        self.add(self.L.conv8_gemm_f32, ptr(X), Bn, L, Cin, pad, ptr(Wp), Cout, ptr(self.ws), ldp, ss, ns)
+        return Slabs(ptr(self.ws), ns, ss, ldp, M, Cout)
+
+    # -- epilogues ----------------------------------------------------------------------------------------
+    def affine_act(self, s: Slabs, scale, shift, act: int, out, ldo: int):
+        self.add(self.L.ep_affine_act, s.ptr, s.ns, s.ss, s.ldp, s.M, s.N, ptr(scale), ptr(shift), act, ptr(out), ldo)
+
+    def lrelu_drop(self, s: Slabs, bias, mask, ldmask: int, H, ldh: int, D, ldd: int, slope: float = 0.2):
+        self.add(self.L.ep_lrelu_drop, s.ptr, s.ns, s.ss, s.ldp, s.M, s.N, ptr(bias), ptr(mask), ldmask, slope,
+                 ptr(H), ldh, ptr(D), ldd)
+
+    def mul(self, s: Slabs, D, ldd: int, dmode: int, colscale, rowscale, out, out2, ldo: int):
+        self.add(self.L.ep_mul, s.ptr, s.ns, s.ss, s.ldp, s.M, s.N, ptr(D), ldd, dmode, ptr(colscale), ptr(rowscale),
+                 ptr(out), ptr(out2), ldo)
