@@ -1,0 +1,232 @@
+#!/usr/bin/env python3
+"""bench.py -- wfd-gan hot path on MI355X.
+
+    python bench.py --gpus N --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
+
+A step = one pass of the reference loop body (src/mlp_df_wgan_train.py:182-275) over one batch of synthetic input:
+a D-step, plus a G-step when i % n_critic == 0.  Workload = BASELINE.json configs[1]: 100 sites x 1000 instances,
+L = 1400 (S = 1401), batch 64 per GPU, latent 500, n_critic 3, fp32.  Inputs are resident in HBM before the timed
+region.  N > 1: data parallel (weak scaling: 64 rows per GPU), gradient all-reduce over RCCL.
+
+Prints ONE JSON line (rank 0) with the contract fields plus `roofline` (dominant kernel = the fp32 MFMA GEMM core,
+timed live with HIP events around each launch in an instrumented eager pass of the same step), `cpu_baseline` (the
+oracle = CPU restatement of the reference loop, timed on this host; rank 0, N = 1 only) and `sampling`
+(generated traces/s of the bulk sampler, the second half of BASELINE.json's metric).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+PEAK_F32_MFMA_TFLOPS = 157.3      # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, 64 FLOP/clk/SIMD
+PEAK_HBM_GBS = 8000.0
+
+
+def synth_dataset_device(n_cls, n_inst, L, n_lo, max_out, max_in, seed, device):
+    """BASELINE.md config-2 recipe generated on the device: row = [n, alternating U{1..max_out}/U{1..max_in}, 0...]."""
+    g = torch.Generator(device=device)
+    g.manual_seed(seed)
+    N = n_cls * n_inst
+    n = torch.randint(n_lo, L + 1, (N,), generator=g, device=device)
+    out_v = torch.randint(1, max_out + 1, (N, L), generator=g, device=device)
+    in_v = torch.randint(1, max_in + 1, (N, L), generator=g, device=device)
+    odd = (torch.arange(L, device=device) % 2 == 0)          # body column 0 is feature column 1 = outgoing
+    body = torch.where(odd.unsqueeze(0), out_v, in_v).to(torch.float32)
+    body = body * (torch.arange(L, device=device).unsqueeze(0) < n.unsqueeze(1))
+    X = torch.cat([n.to(torch.float32).unsqueeze(1), body], 1)
+    y = torch.arange(n_cls, device=device).repeat_interleave(n_inst)
+    return X, y
+
+
+def build_engine(args, rank, world, device):
+    from wfd_gan_amd.engine import TrainEngine
+    from wfd_gan_amd.model import DF, Discriminator, Generator
+    S, C, Z, B = args.seq_len, args.classes, args.latent_dim, args.batch
+    X, y = synth_dataset_device(C, args.inst, S - 1, 50, 75, 179, 1000 + rank, device)
+    dmin, dmax = X.min(0).values, X.max(0).values
+    rngv = torch.where(dmax > dmin, dmax - dmin, torch.ones_like(dmax))
+    Xs = (X - dmin) / rngv
+    torch.manual_seed(0)                      # same replicas on every rank
+    G = Generator(S, C, Z, float(dmin[0]), float(dmax[0]))
+    D = Discriminator(S, C)
+    F = DF(S - 1, C)
+    pg = None
+    eng = TrainEngine(S, C, Z, B, float(dmin[0]), float(dmax[0]), G.state_dict(), D.state_dict(), F.state_dict(),
+                      lr=2e-4, alpha=0.02, n_critic=3, penalty=args.penalty, device=device, seed=1234 + rank,
+                      process_group=pg, world_size=world)
+    eng.attach_dataset(Xs, y, shuffle_seed=rank)
+    return eng, (dmin.double().cpu().numpy(), dmax.double().cpu().numpy())
+
+
+def run_steps(eng, start, n):
+    for i in range(start, start + n):
+        eng.iteration(i)
+        if (i + 1) % eng.iters_per_epoch == 0:
+            eng.reshuffle()
+
+
+def gemm_roofline(eng, n_iters=6):
+    """Instrumented eager pass: HIP events (torch.cuda.Event on the launch stream) around every GEMM-core launch of
+    the same fast-mode plans; returns achieved TFLOP/s = sum(flops) / sum(duration) and the per-launch averages."""
+    from wfd_gan_amd.plan import HOST
+    L = eng.L
+    gemm_fns = {L.gemm_f32: "gemm", L.conv8_gemm_f32: "conv"}
+    stream = torch.cuda.current_stream().cuda_stream
+    recs = []
+    for it in range(n_iters):
+        plans = [eng.fast_d] + ([eng.fast_g] if it % eng.n_critic == 0 else [])
+        for plan in plans:
+            for fn, a in plan.calls:
+                if fn is HOST:
+                    a[0]()
+                    continue
+                kind = gemm_fns.get(fn)
+                if kind is None:
+                    fn(*a, stream)
+                    continue
+                if kind == "gemm":
+                    M, N, K = a[8], a[9], a[10]
+                else:
+                    M, N, K = a[1] * a[2], a[6], 8 * a[3]
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                fn(*a, stream)
+                e1.record()
+                recs.append((2.0 * M * N * K, e0, e1))
+    torch.cuda.synchronize()
+    flops = sum(r[0] for r in recs)
+    ms = sum(r[1].elapsed_time(r[2]) for r in recs)
+    n = len(recs)
+    return dict(launches=n, avg_flops=flops / n, avg_us=ms * 1e3 / n, tflops=flops / (ms * 1e-3) / 1e12)
+
+
+def cpu_baseline(args, seconds=20.0):
+    """The oracle (CPU restatement of the reference loop, pinned bit-exact against the reference) on this host."""
+    from oracle import wfdgan_oracle as O
+    S, C, Z, B = args.seq_len, args.classes, args.latent_dim, args.batch
+    threads = min(16, os.cpu_count() or 1)
+    torch.set_num_threads(threads)
+    X, y = O.synth_dataset(C, 8, S - 1, 50, 75, 179, seed=0)
+    dmin, dmax = X.min(0), X.max(0)
+    scale, min_ = O.scaler_params(dmin, dmax)
+    Xs = torch.from_numpy(X * scale + min_)
+    yt = torch.from_numpy(y)
+    st = O.make_state(S, C, Z, dmin[0], dmax[0], seed=0, df_seed=1)
+    rng = np.random.RandomState(0)
+    n, t0 = 0, None
+    i = 0
+    while True:
+        idx = rng.randint(0, Xs.shape[0], B)
+        z = torch.from_numpy(rng.normal(0, 1, (B, Z))).float()
+        O.iteration(st, Xs[idx], yt[idx], z, do_g=(i % 3 == 0))
+        i += 1
+        if i == 3:                      # warm-up of 3 iterations, then time whole groups of 3
+            t0, n = time.perf_counter(), 0
+        elif i > 3:
+            n += 1
+            if n % 3 == 0 and time.perf_counter() - t0 > seconds:
+                break
+    dt = time.perf_counter() - t0
+    return dict(value=n / dt, unit="iterations/s", cores=threads, kind="port",
+                sample=f"{n} iterations of the same config-2 step (B={B}, S={S}) on {threads} host threads")
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=300)
+    ap.add_argument("--warmup", type=int, default=30)
+    ap.add_argument("--batch", type=int, default=64)
+    ap.add_argument("--seq_len", type=int, default=1401)
+    ap.add_argument("--classes", type=int, default=100)
+    ap.add_argument("--inst", type=int, default=1000)
+    ap.add_argument("--latent_dim", type=int, default=500)
+    ap.add_argument("--penalty", default="div", choices=["div", "gp"])
+    ap.add_argument("--no-graph", action="store_true")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-sampling", action="store_true")
+    ap.add_argument("--cpu-seconds", type=float, default=20.0)
+    args = ap.parse_args()
+
+    from wfd_gan_amd import parallel
+    rank, world, local = parallel.init_from_env()
+    if world != args.gpus and world > 1:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    device = torch.device(f"cuda:{local}")
+    torch.cuda.set_device(device)
+
+    eng, (dmin, dmax) = build_engine(args, rank, world, device)
+    if not args.no_graph:
+        eng.capture_graphs()
+    run_steps(eng, 0, args.warmup)
+
+    def barrier():
+        if world > 1:
+            torch.distributed.barrier()
+        torch.cuda.synchronize()
+
+    barrier()
+    t0 = time.perf_counter()
+    run_steps(eng, args.warmup, args.steps)
+    barrier()
+    dt = parallel.max_over_ranks(time.perf_counter() - t0, device)
+    eng.check_length_index()
+    ms_per_step = dt * 1e3 / args.steps
+    its = args.steps / dt
+
+    roof = gemm_roofline(eng)
+    samp = None
+    if not args.no_sampling:
+        from wfd_gan_amd.sampler import BulkSampler
+        chunk = 8192
+        bs = BulkSampler(eng.generator_state(), args.seq_len, args.classes, args.latent_dim, dmin, dmax, chunk=chunk,
+                         device=device, seed=99 + rank)
+        bs.capture()
+        labels = (torch.arange(chunk, device=device) % args.classes).to(torch.int32)
+        for _ in range(2):
+            bs.run_chunk(labels)
+        barrier()
+        t1 = time.perf_counter()
+        nchunks = 8
+        for _ in range(nchunks):
+            bs.run_chunk(labels)
+        barrier()
+        sdt = parallel.max_over_ranks(time.perf_counter() - t1, device)
+        samp = dict(value=world * nchunks * chunk / sdt, unit="traces/s", chunk=chunk,
+                    note="int32 burst vectors left on device; eval generator + inverse-scale/rint/trim epilogue")
+
+    if rank == 0:
+        out = {
+            "metric": "WGAN train iterations/s (100-class, L=1400, B=64/GPU, fp32; D-step every iter, G-step every 3rd)",
+            "value": its * 1.0, "unit": "iterations/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "configs[1]: 100 sites x 1000 inst synthetic bursts, L=1400 (S=1401), batch "
+                                   f"{args.batch}/GPU, latent {args.latent_dim}, n_critic 3, alpha 0.02, RMSprop 2e-4, "
+                                   f"penalty={args.penalty} ({'W-div k=2 p=6, what the reference runs' if args.penalty == 'div' else 'WGAN-GP interpolate'})",
+                       "global_batch": args.batch * world, "samples_per_s": its * args.batch * world,
+                       "parallelism": f"dp{world}", "graphs": not args.no_graph},
+            "roofline": {"bound": "mfma", "achieved": roof["tflops"], "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
+                         "frac": roof["tflops"] / PEAK_F32_MFMA_TFLOPS, "traffic": None,
+                         "kernel": "gemm_f32_kernel (fp32 MFMA core, all layouts)", "launches_timed": roof["launches"],
+                         "avg_flops_per_launch": roof["avg_flops"], "avg_us_per_launch": roof["avg_us"]},
+        }
+        if samp:
+            out["sampling"] = samp
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(args, args.cpu_seconds)
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        torch.distributed.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

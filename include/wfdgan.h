@@ -141,18 +141,24 @@ int wfd_df_conv1_bwd(const float* dC, int Bn, int L, int Cout, const float* W, f
 
 /* ---- data side ---------------------------------------------------------------------------------------- */
 
-/* nn.Dropout keep-mask values {0, 1/(1-p)} from Philox4x32-10 (fast mode; parity tests pass explicit masks) */
-int wfd_rng_dropout_mask(float* out, long n, float p, unsigned long long seed, unsigned long long offset,
-                         void* stream);
+/* nn.Dropout keep-mask values {0, 1/(1-p)} from Philox4x32-10 (fast mode; parity tests pass explicit masks).
+ * The Philox counter is state[0] + base, with state in DEVICE memory (may be NULL = 0) so that a captured
+ * graph draws fresh numbers on every replay; wfd_iter_advance moves it. */
+int wfd_rng_dropout_mask(float* out, long n, float p, unsigned long long seed, const unsigned long long* state,
+                         unsigned long long base, void* stream);
 
 /* z ~ N(0,1) (np.random.normal, src/mlp_df_wgan_train.py:194; np.random.randn, src/generate.py:53) on device */
-int wfd_rng_normal_rows(float* out, int ld, int M, int Z, unsigned long long seed, unsigned long long offset,
-                        void* stream);
+int wfd_rng_normal_rows(float* out, int ld, int M, int Z, unsigned long long seed, const unsigned long long* state,
+                        unsigned long long base, void* stream);
+
+/* state[0] += inc0 (Philox counter), state[1] += inc1 (cursor into the epoch permutation) */
+int wfd_iter_advance(unsigned long long* state, unsigned long long inc0, unsigned long long inc1, void* stream);
 
 /* one training batch: rows idx[] of the resident dataset + one-hot labels into the real / fake / generator-input
- * buffers (DataLoader + np.eye(class_dim)[c], src/mlp_df_wgan_train.py:182-186) */
-int wfd_gather_batch(const float* X, int ldX, const int* y, const long long* idx, int B, int S, int C, float* real,
-                     float* fake, int ldd, float* zin, int ldz, int Z, int* labels_out, void* stream);
+ * buffers (DataLoader + np.eye(class_dim)[c], src/mlp_df_wgan_train.py:182-186); row b reads idx[state[1] + b] */
+int wfd_gather_batch(const float* X, int ldX, const int* y, const long long* idx, const unsigned long long* state,
+                     int B, int S, int C, float* real, float* fake, int ldd, float* zin, int ldz, int Z,
+                     int* labels_out, void* stream);
 
 int wfd_onehot_rows(const int* labels, int M, int C, float* out, int ld, int col0, void* stream);
 

@@ -21,7 +21,8 @@ __device__ __forceinline__ float u01(uint32_t x) { return ((x >> 8) + 0.5f) * (1
 
 // dropout keep-masks with values {0, 1/(1-p)} (what nn.Dropout multiplies by); n multiple of 4 handled generally
 __global__ void rng_dropout_mask_kernel(float* __restrict__ out, long n, float p, unsigned long long seed,
-                                        unsigned long long offset) {
+                                        const unsigned long long* __restrict__ state, unsigned long long base) {
+    const unsigned long long offset = (state ? state[0] : 0ull) + base;
     const float keep = 1.0f / (1.0f - p);
     const long stride = (long)gridDim.x * blockDim.x;
     for (long q = (long)blockIdx.x * blockDim.x + threadIdx.x; q * 4 < n; q += stride) {
@@ -37,7 +38,8 @@ __global__ void rng_dropout_mask_kernel(float* __restrict__ out, long n, float p
 
 // standard normal into rows of a strided matrix: out[m][0..Z) (Box-Muller on Philox uniforms)
 __global__ void rng_normal_rows_kernel(float* __restrict__ out, int ld, int M, int Z, unsigned long long seed,
-                                       unsigned long long offset) {
+                                       const unsigned long long* __restrict__ state, unsigned long long base) {
+    const unsigned long long offset = (state ? state[0] : 0ull) + base;
     const long total4 = ((long)M * Z + 3) / 4;
     const long stride = (long)gridDim.x * blockDim.x;
     for (long q = (long)blockIdx.x * blockDim.x + threadIdx.x; q < total4; q += stride) {
@@ -61,11 +63,12 @@ __global__ void rng_normal_rows_kernel(float* __restrict__ out, int ld, int M, i
 //   real[b][0..S) = X[idx[b]][0..S);  real[b][S..S+C) = onehot(y[idx[b]]);  fake[b][S..S+C) = same one-hot
 //   zin[b][Z..Z+C) = same one-hot;  labels_out[b] = y[idx[b]]
 __global__ void gather_batch_kernel(const float* __restrict__ X, int ldX, const int* __restrict__ y,
-                                    const long long* __restrict__ idx, int S, int C, float* __restrict__ real,
+                                    const long long* __restrict__ idx, const unsigned long long* __restrict__ state,
+                                    int S, int C, float* __restrict__ real,
                                     float* __restrict__ fake, int ldd, float* __restrict__ zin, int ldz, int Z,
                                     int* __restrict__ labels_out) {
     const int b = blockIdx.x;
-    const long long src = idx[b];
+    const long long src = idx[(state ? (long long)state[1] : 0ll) + b];
     const int lab = y[src];
     for (int j = threadIdx.x; j < S; j += blockDim.x) real[(long)b * ldd + j] = X[src * ldX + j];
     for (int c = threadIdx.x; c < C; c += blockDim.x) {
@@ -75,6 +78,12 @@ __global__ void gather_batch_kernel(const float* __restrict__ X, int ldX, const 
         if (zin) zin[(long)b * ldz + Z + c] = v;
     }
     if (threadIdx.x == 0 && labels_out) labels_out[b] = lab;
+}
+
+// per-iteration device state: state[0] = Philox counter offset, state[1] = cursor into the epoch permutation
+__global__ void iter_advance_kernel(unsigned long long* __restrict__ state, unsigned long long inc0,
+                                    unsigned long long inc1) {
+    if (threadIdx.x == 0 && blockIdx.x == 0) { state[0] += inc0; state[1] += inc1; }
 }
 
 // one-hot class columns for the sampler: zin[m][Z..Z+C) = onehot(labels[m])
@@ -135,34 +144,42 @@ __global__ void sample_post_kernel(const float* __restrict__ Y, int ldy, int S, 
 
 extern "C" {
 
-int wfd_rng_dropout_mask(float* out, long n, float p, unsigned long long seed, unsigned long long offset,
-                         void* stream) {
+int wfd_rng_dropout_mask(float* out, long n, float p, unsigned long long seed, const unsigned long long* state,
+                         unsigned long long base, void* stream) {
     if (!out || n <= 0 || p < 0.f || p >= 1.f) return WFD_ERR_ARG;
     long blocks = (n / 4 + 255) / 256;
     if (blocks > 2048) blocks = 2048;
     if (blocks < 1) blocks = 1;
     hipLaunchKernelGGL(rng_dropout_mask_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, out, n, p,
-                       seed, offset);
+                       seed, state, base);
     WFD_CHECK_LAUNCH();
     return WFD_OK;
 }
 
-int wfd_rng_normal_rows(float* out, int ld, int M, int Z, unsigned long long seed, unsigned long long offset,
-                        void* stream) {
+int wfd_rng_normal_rows(float* out, int ld, int M, int Z, unsigned long long seed, const unsigned long long* state,
+                        unsigned long long base, void* stream) {
     if (!out || M <= 0 || Z <= 0 || ld < Z) return WFD_ERR_ARG;
     long blocks = (((long)M * Z + 3) / 4 + 255) / 256;
     if (blocks > 2048) blocks = 2048;
     hipLaunchKernelGGL(rng_normal_rows_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, out, ld, M, Z,
-                       seed, offset);
+                       seed, state, base);
     WFD_CHECK_LAUNCH();
     return WFD_OK;
 }
 
-int wfd_gather_batch(const float* X, int ldX, const int* y, const long long* idx, int B, int S, int C, float* real,
-                     float* fake, int ldd, float* zin, int ldz, int Z, int* labels_out, void* stream) {
+int wfd_gather_batch(const float* X, int ldX, const int* y, const long long* idx, const unsigned long long* state,
+                     int B, int S, int C, float* real, float* fake, int ldd, float* zin, int ldz, int Z,
+                     int* labels_out, void* stream) {
     if (!X || !y || !idx || !real || B <= 0) return WFD_ERR_ARG;
-    hipLaunchKernelGGL(gather_batch_kernel, dim3(B), dim3(256), 0, (hipStream_t)stream, X, ldX, y, idx, S, C, real, fake,
-                       ldd, zin, ldz, Z, labels_out);
+    hipLaunchKernelGGL(gather_batch_kernel, dim3(B), dim3(256), 0, (hipStream_t)stream, X, ldX, y, idx, state, S, C, real,
+                       fake, ldd, zin, ldz, Z, labels_out);
+    WFD_CHECK_LAUNCH();
+    return WFD_OK;
+}
+
+int wfd_iter_advance(unsigned long long* state, unsigned long long inc0, unsigned long long inc1, void* stream) {
+    if (!state) return WFD_ERR_ARG;
+    hipLaunchKernelGGL(iter_advance_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, state, inc0, inc1);
     WFD_CHECK_LAUNCH();
     return WFD_OK;
 }

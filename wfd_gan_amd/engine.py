@@ -112,6 +112,42 @@ class ObserverDF:
         assert tuple(self.fc_w.shape) == (num_classes, 512)
 
 
+def observer_buffers(df: "ObserverDF", B: int, device) -> Dict[str, object]:
+    """Activation buffers of one DF forward on B rows (channels-last)."""
+    z = lambda *s: torch.zeros(*s, dtype=torch.float32, device=device)
+    Ls = df.Ls
+    ldc = rup(df.C, 4)
+    return dict(
+        Y=[z(B * Ls[0], 32), z(B * Ls[0], 32), z(B * Ls[1], 64), z(B * Ls[1], 64), z(B * Ls[2], 128),
+           z(B * Ls[2], 128), z(B * Ls[3], 256)],
+        PO=[z(B * Ls[1], 32), z(B * Ls[2], 64), z(B * Ls[3], 128), z(B * Ls[4], 256)],
+        F1=z(B, 512), F2=z(B, 512), LOG=z(B, ldc), ldc=ldc)
+
+
+def observer_forward(p: Plan, df: "ObserverDF", X, ldx: int, xoff: int, B: int, Y, PO, F1, F2, LOG, ldc: int):
+    """DF.forward in eval mode (src/model.py:198-206) on x[b][l] = X[b*ldx + xoff + l] -> logits LOG[B][ldc]."""
+    L = p.L
+    Ls, cv = df.Ls, df.convs
+    p.add(L.df_conv1_fwd, ptr(X), ldx, xoff, B, Ls[0], ptr(cv[0]["w_raw"]), ptr(cv[0]["scale"]), ptr(cv[0]["shift"]),
+          cv[0]["act"], ptr(Y[0]), 32)
+    cur, lvl, pi = Y[0], 0, 0
+    for k in range(1, 7):
+        c = cv[k]
+        s = p.conv8(cur, B, Ls[lvl], c["cin"], 3, c["w"], c["cout"])
+        p.affine_act(s, c["scale"], c["shift"], c["act"], Y[k], c["cout"])
+        cur = Y[k]
+        if c["pool"]:
+            p.add(L.df_pool8_fwd, ptr(cur), B, Ls[lvl], c["cout"], ptr(PO[pi]))
+            cur, lvl, pi = PO[pi], lvl + 1, pi + 1
+    kin = 256 * Ls[4]
+    s = p.gemm(NT, PO[3], kin, df.fc1_w, kin, B, 512, kin)
+    p.affine_act(s, df.fc1_scale, df.fc1_shift, ACT_RELU, F1, 512)
+    s = p.gemm(NT, F1, 512, df.fc2_w, 512, B, 512, 512)
+    p.affine_act(s, df.fc2_scale, df.fc2_shift, ACT_RELU, F2, 512)
+    s = p.gemm(NT, F2, 512, df.fc_w, 512, B, df.C, 512)
+    p.affine_act(s, None, df.fc_b, ACT_NONE, LOG, ldc)
+
+
 class TrainEngine:
     """One rank's state for the training hot path.  ``B`` is the per-rank batch (rows per side)."""
 
@@ -119,7 +155,7 @@ class TrainEngine:
                  scaler_max: float, G_state: Dict[str, torch.Tensor], D_state: Dict[str, torch.Tensor],
                  DF_state: Dict[str, torch.Tensor], lr: float = 2e-4, alpha: float = 0.02, n_critic: int = 3,
                  penalty: str = "div", lambda_gp: float = 10.0, device="cuda:0", global_batch: Optional[int] = None,
-                 seed: int = 0, workspace_mb: int = 256):
+                 seed: int = 0, workspace_mb: int = 256, process_group=None, world_size: int = 1):
         if not torch.cuda.is_available():
             raise RuntimeError("wfd_gan_amd.TrainEngine needs a HIP device: there is no CPU path")
         if penalty not in ("div", "gp"):
@@ -137,6 +173,9 @@ class TrainEngine:
         self.scaler_min, self.scaler_max = scaler_min, scaler_max
         self.seed = seed
         self.rng_offset = 0
+        # data parallel (DDP semantics): every rank computes its local-batch losses and gradients, the flat
+        # gradient buffers are all-reduced (sum) and RMSprop scales them by 1/world_size.
+        self.pg, self.world = process_group, int(world_size)
         self.nbt = {"model.3": 0, "model.6": 0}
         dev = self.dev
         f32 = dict(dtype=torch.float32, device=dev)
@@ -314,36 +353,22 @@ class TrainEngine:
         p.add(self.L.colsum, ptr(b["H3"]), 512, M, 512, ptr(b["DV"]), ptr(D.g["model.9.weight"]), 1)
         p.add(self.L.colsum, ptr(b["DV"]), 1, M, 1, 0, ptr(D.g["model.9.bias"]), 0)
         self._grad_sync_hook(p, "D")
-        p.add(self.L.rmsprop, ptr(D.flat), ptr(D.grad), ptr(D.sq), D.numel, self.lr, 0.99, 1e-8, 1.0)
+        p.add(self.L.rmsprop, ptr(D.flat), ptr(D.grad), ptr(D.sq), D.numel, self.lr, 0.99, 1e-8, 1.0 / self.world)
         return p
 
     def _grad_sync_hook(self, p: Plan, which: str):
-        return
+        if self.world > 1:
+            from .parallel import allreduce_sum_
+            flat = self.Dp.grad if which == "D" else self.Gp.grad
+            p.host(lambda: allreduce_sum_(flat, self.pg))
 
     def _observer(self, p: Plan):
         """DF forward on fake[:, 1:], masked CE, and the input gradient dDF (src/mlp_df_wgan_train.py:251-263,273)."""
         B, b, df = self.B, self.buf, self.df
         Ls, Y, PO, DC, DPO = df.Ls, b["Y"], b["PO"], b["DC"], b["DPO"]
         cv = df.convs
-        # ---- forward
-        p.add(self.L.df_conv1_fwd, ptr(self.fake_rows), self.ldx, 1, B, Ls[0], ptr(cv[0]["w_raw"]),
-              ptr(cv[0]["scale"]), ptr(cv[0]["shift"]), cv[0]["act"], ptr(Y[0]), 32)
-        cur, lvl, pi = Y[0], 0, 0
-        for k in range(1, 7):
-            c = cv[k]
-            s = p.conv8(cur, B, Ls[lvl], c["cin"], 3, c["w"], c["cout"])
-            p.affine_act(s, c["scale"], c["shift"], c["act"], Y[k], c["cout"])
-            cur = Y[k]
-            if c["pool"]:
-                p.add(self.L.df_pool8_fwd, ptr(cur), B, Ls[lvl], c["cout"], ptr(PO[pi]))
-                cur, lvl, pi = PO[pi], lvl + 1, pi + 1
         kin = 256 * Ls[4]
-        s = p.gemm(NT, PO[3], kin, df.fc1_w, kin, B, 512, kin)
-        p.affine_act(s, df.fc1_scale, df.fc1_shift, ACT_RELU, b["F1"], 512)
-        s = p.gemm(NT, b["F1"], 512, df.fc2_w, 512, B, 512, 512)
-        p.affine_act(s, df.fc2_scale, df.fc2_shift, ACT_RELU, b["F2"], 512)
-        s = p.gemm(NT, b["F2"], 512, df.fc_w, 512, B, self.C, 512)
-        p.affine_act(s, None, df.fc_b, ACT_NONE, b["LOG"], self.ldc)
+        observer_forward(p, df, self.fake_rows, self.ldx, 1, B, Y, PO, b["F1"], b["F2"], b["LOG"], self.ldc)
         self._nsel_sync_hook(p)
         p.add(self.L.masked_ce, ptr(b["LOG"]), self.ldc, B, self.C, ptr(b["labels"]), ptr(b["gV"]),
               b["ghead"].data_ptr() + 4, self.alpha, ptr(b["CE"]), ptr(b["DLOG"]), self.ldc)
@@ -409,7 +434,7 @@ class TrainEngine:
         p.add(self.L.colsum, ptr(b["GDZ1"]), 512, B, 512, 0, ptr(G.g["model.0.bias"]), 0)
         p.gemm(TN, b["GDZ1"], 512, b["ZIN"], self.ldz, 512, Z + C, B, out=G.g["model.0.weight"], ldp=Z + C)
         self._grad_sync_hook(p, "G")
-        p.add(self.L.rmsprop, ptr(G.flat), ptr(G.grad), ptr(G.sq), G.numel, self.lr, 0.99, 1e-8, 1.0)
+        p.add(self.L.rmsprop, ptr(G.flat), ptr(G.grad), ptr(G.sq), G.numel, self.lr, 0.99, 1e-8, 1.0 / self.world)
         return p
 
     def _bn_bwd(self, p: Plan, s: Slabs, i: int, lin: str, bn: str, n: int):
@@ -496,3 +521,108 @@ class TrainEngine:
 
     def discriminator_state(self) -> Dict[str, torch.Tensor]:
         return self.Dp.state()
+
+    # ------------------------------------------------------------------------------------------------------
+    # fast mode: dataset resident in HBM, batch assembly + z + dropout masks drawn on device, HIP-graph replay
+    def attach_dataset(self, X: torch.Tensor, y: torch.Tensor, shuffle_seed: int = 0):
+        """X (N,S) scaled fp32 features and y (N,) int labels, both moved to HBM once (100000 x 1401 fp32 = 560 MB)."""
+        self.data_X = X.to(self.dev, torch.float32).contiguous()
+        self.data_y = y.to(self.dev, torch.int32).contiguous()
+        self.N = self.data_X.shape[0]
+        self.iters_per_epoch = self.N // self.B          # full batches; the trainer handles a ragged tail
+        self.iter_state = torch.zeros(2, dtype=torch.int64, device=self.dev)   # [philox counter, perm cursor]
+        self.perm_gen = torch.Generator(device=self.dev)
+        self.perm_gen.manual_seed(shuffle_seed)
+        self.perm = torch.randperm(self.N, generator=self.perm_gen, device=self.dev)
+        self.fast_d, self.fast_g = self._build_fast_plans()
+
+    def reshuffle(self):
+        """New epoch permutation (DataLoader(shuffle=True), src/mlp_df_wgan_train.py:142-147); cursor back to 0."""
+        self.perm.copy_(torch.randperm(self.N, generator=self.perm_gen, device=self.dev))
+        self.iter_state[1] = 0
+
+    def _build_fast_plans(self):
+        B, S, C, Z, b = self.B, self.S, self.C, self.Z, self.buf
+        st = self.iter_state.data_ptr()
+        gold = 0x9E3779B97F4A7C15
+        pd = Plan(b["ws"])
+        pd.add(self.L.gather_batch, ptr(self.data_X), S, ptr(self.data_y), ptr(self.perm), st, B, S, C,
+               ptr(self.real_rows), ptr(self.fake_rows), self.ldx, ptr(b["ZIN"]), self.ldz, Z, ptr(b["labels"]))
+        pd.add(self.L.rng_normal_rows, ptr(b["ZIN"]), self.ldz, B, Z, (self.seed + 7 * gold) & (2**64 - 1), st, 0)
+        inc = (B * Z + 3) // 4
+        for k, nme in enumerate(("MK1", "MK2", "MK3")):
+            t = b[nme]
+            pd.add(self.L.rng_dropout_mask, ptr(t), t.numel(), 0.2, (self.seed + (k + 1) * gold) & (2**64 - 1), st, 0)
+            inc = max(inc, (t.numel() + 3) // 4)
+        pd.calls += self.plan_d.calls
+        pd.add(self.L.iter_advance, st, inc, B)
+        pg = Plan(b["ws"])
+        for k, nme in enumerate(("gMK1", "gMK2", "gMK3")):
+            t = b[nme]
+            pg.add(self.L.rng_dropout_mask, ptr(t), t.numel(), 0.2, (self.seed + (k + 4) * gold) & (2**64 - 1), st, 0)
+        pg.calls += self.plan_g.calls
+        pg.add(self.L.iter_advance, st, inc, 0)
+        return pd, pg
+
+    def _snapshot(self):
+        snap = dict(G=self.Gp.flat.clone(), Gsq=self.Gp.sq.clone(), D=self.Dp.flat.clone(), Dsq=self.Dp.sq.clone(),
+                    bn={k: v.clone() for k, v in self.Gbuf.items()}, st=self.iter_state.clone(),
+                    dacc=self.buf["dacc"].clone(), gacc=self.buf["gacc"].clone(), nbt=dict(self.nbt))
+        return snap
+
+    def _restore(self, snap):
+        self.Gp.flat.copy_(snap["G"]); self.Gp.sq.copy_(snap["Gsq"])
+        self.Dp.flat.copy_(snap["D"]); self.Dp.sq.copy_(snap["Dsq"])
+        for k, v in snap["bn"].items():
+            self.Gbuf[k].copy_(v)
+        self.iter_state.copy_(snap["st"])
+        self.buf["dacc"].copy_(snap["dacc"]); self.buf["gacc"].copy_(snap["gacc"])
+        self.nbt = dict(snap["nbt"])
+
+    def capture_graphs(self):
+        """Capture the D-step and the G-step as HIP graphs (one launch each per replay).  A warm-up run loads the
+        kernels first; training state is restored afterwards so the capture does not consume an iteration."""
+        snap = self._snapshot()
+        side = torch.cuda.Stream(device=self.dev)
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            self.fast_d.run()
+            self.fast_g.run()
+        torch.cuda.current_stream().wait_stream(side)
+        torch.cuda.synchronize()
+        self.graph_d = self._capture_stages(self.fast_d)
+        self.graph_g = self._capture_stages(self.fast_g)
+        torch.cuda.synchronize()
+        self._restore(snap)
+
+    @staticmethod
+    def _capture_stages(plan: Plan):
+        """One HIP graph per run of launches; host actions (collectives) stay eager between the replays."""
+        out = []
+        for st in plan.stages():
+            if isinstance(st, Plan):
+                g = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g):
+                    st.run()
+                out.append(g.replay)
+            else:
+                out.append(st)
+        return out
+
+    def iteration(self, i: int):
+        """One pass of the reference loop body in fast mode: D-step, plus a G-step when i % n_critic == 0."""
+        do_g = (i % self.n_critic == 0)
+        if self.graph_d is not None:
+            for st in self.graph_d:
+                st()
+            if do_g:
+                for st in self.graph_g:
+                    st()
+        else:
+            self.fast_d.run()
+            if do_g:
+                self.fast_g.run()
+        k = 2 if do_g else 1
+        self.nbt["model.3"] += k
+        self.nbt["model.6"] += k
+        return do_g

@@ -16,6 +16,7 @@ from ._lib import lib
 Slabs = namedtuple("Slabs", "ptr ns ss ldp M N")
 
 NT, NN, TN = 0, 1, 2
+HOST = object()          # marker: plan entry executed on the host (e.g. a torch.distributed collective)
 ACT_NONE, ACT_RELU, ACT_ELU, ACT_SIGMOID = 0, 1, 2, 3
 DM_NONE, DM_MUL, DM_RELU, DM_ELU = 0, 1, 2, 3
 
@@ -46,11 +47,34 @@ class Plan:
     def add(self, fn, *args):
         self.calls.append((fn, args))
 
+    def host(self, thunk):
+        """A host-side action between launches (a collective): splits the plan into separately captured stages."""
+        self.calls.append((HOST, (thunk,)))
+
     def run(self, stream: Optional[int] = None):
         if stream is None:
             stream = torch.cuda.current_stream().cuda_stream
         for fn, a in self.calls:
-            fn(*a, stream)
+            if fn is HOST:
+                a[0]()
+                stream = torch.cuda.current_stream().cuda_stream
+            else:
+                fn(*a, stream)
+
+    def stages(self):
+        """[Plan | thunk, ...]: maximal runs of launches separated by host actions."""
+        out, cur = [], Plan(self.ws)
+        for fn, a in self.calls:
+            if fn is HOST:
+                if len(cur):
+                    out.append(cur)
+                out.append(a[0])
+                cur = Plan(self.ws)
+            else:
+                cur.calls.append((fn, a))
+        if len(cur):
+            out.append(cur)
+        return out
 
     def __len__(self):
         return len(self.calls)
