@@ -24,36 +24,89 @@ __device__ __forceinline__ float slab_sum(const float* __restrict__ P, int ns, l
 __device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + __expf(-x)); }
 
 // ---------------------------------------------------------------------------------------------------------
+// Element-wise epilogues: one thread per 4 consecutive columns (float4 when every operand is 16-byte aligned),
+// flat over M x N/4 so that tall-skinny conv outputs (M = B*L, N = 32) and short-wide MLP outputs fill the chip.
+template <bool VEC>
+__device__ __forceinline__ float4 slab_sum4(const float* __restrict__ P, int ns, long ss, long idx, int nvalid) {
+    float4 a;
+    if constexpr (VEC) {
+        a = *reinterpret_cast<const float4*>(P + idx);
+        for (int z = 1; z < ns; ++z) {
+            const float4 b = *reinterpret_cast<const float4*>(P + (long)z * ss + idx);
+            a.x += b.x; a.y += b.y; a.z += b.z; a.w += b.w;
+        }
+    } else {
+        float t[4] = {0.f, 0.f, 0.f, 0.f};
+        for (int k = 0; k < nvalid; ++k) t[k] = slab_sum(P, ns, ss, idx + k);
+        a = make_float4(t[0], t[1], t[2], t[3]);
+    }
+    return a;
+}
+template <bool VEC>
+__device__ __forceinline__ float4 load4(const float* __restrict__ p, int nvalid) {
+    if constexpr (VEC) return *reinterpret_cast<const float4*>(p);
+    float t[4] = {0.f, 0.f, 0.f, 0.f};
+    for (int k = 0; k < nvalid; ++k) t[k] = p[k];
+    return make_float4(t[0], t[1], t[2], t[3]);
+}
+template <bool VEC>
+__device__ __forceinline__ void store4(float* __restrict__ p, float4 v, int nvalid) {
+    if constexpr (VEC) { *reinterpret_cast<float4*>(p) = v; return; }
+    const float t[4] = {v.x, v.y, v.z, v.w};
+    for (int k = 0; k < nvalid; ++k) p[k] = t[k];
+}
+__device__ __forceinline__ float act_apply(float v, int act) {
+    if (act == 1) return fmaxf(v, 0.f);
+    if (act == 2) return v > 0.f ? v : expm1f(v);
+    if (act == 3) return 1.0f / (1.0f + expf(-v));
+    return v;
+}
+
 // out[m][n] = act(sumP * scale[n] + shift[n]);  act: 0 none, 1 relu, 2 elu, 3 sigmoid
+template <bool VEC>
 __global__ void ep_affine_act_kernel(const float* __restrict__ P, int ns, long ss, int ldp, int M, int N,
                                      const float* __restrict__ scale, const float* __restrict__ shift, int act,
                                      float* __restrict__ out, int ldo) {
-    const int n = blockIdx.x * blockDim.x + threadIdx.x;
-    if (n >= N) return;
-    const float sc = scale ? scale[n] : 1.f, sh = shift ? shift[n] : 0.f;
-    for (int m = blockIdx.y; m < M; m += gridDim.y) {
-        float v = slab_sum(P, ns, ss, (long)m * ldp + n);
-        v = scale ? __fmaf_rn(v, sc, sh) : v + sh;
-        if (act == 1) v = fmaxf(v, 0.f);
-        else if (act == 2) v = v > 0.f ? v : expm1f(v);
-        else if (act == 3) v = 1.0f / (1.0f + expf(-v));
-        out[(long)m * ldo + n] = v;
+    const int n4 = (N + 3) >> 2;
+    const long total = (long)M * n4;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int m = (int)(i / n4), n = (int)(i - (long)m * n4) * 4, nv = min(4, N - n);
+        float4 v = slab_sum4<VEC>(P, ns, ss, (long)m * ldp + n, nv);
+        float r[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            if (k < nv) {
+                const float sh = shift ? shift[n + k] : 0.f;
+                r[k] = scale ? __fmaf_rn(r[k], scale[n + k], sh) : r[k] + sh;
+                r[k] = act_apply(r[k], act);
+            }
+        }
+        store4<VEC>(out + (long)m * ldo + n, make_float4(r[0], r[1], r[2], r[3]), nv);
     }
 }
 
 // Discriminator hidden layer: z = sumP + b; h = leaky(z) * mask; d = mask * (z > 0 ? 1 : slope)
+template <bool VEC>
 __global__ void ep_lrelu_drop_kernel(const float* __restrict__ P, int ns, long ss, int ldp, int M, int N,
                                      const float* __restrict__ bias, const float* __restrict__ mask, int ldmask,
                                      float slope, float* __restrict__ H, int ldh, float* __restrict__ D, int ldd) {
-    const int n = blockIdx.x * blockDim.x + threadIdx.x;
-    if (n >= N) return;
-    const float b = bias[n];
-    for (int m = blockIdx.y; m < M; m += gridDim.y) {
-        const float z = slab_sum(P, ns, ss, (long)m * ldp + n) + b;
-        const float mk = mask[(long)m * ldmask + n];
-        const float lr = z > 0.f ? z : z * slope;
-        H[(long)m * ldh + n] = lr * mk;
-        D[(long)m * ldd + n] = z > 0.f ? mk : mk * slope;
+    const int n4 = (N + 3) >> 2;
+    const long total = (long)M * n4;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int m = (int)(i / n4), n = (int)(i - (long)m * n4) * 4, nv = min(4, N - n);
+        const float4 v = slab_sum4<VEC>(P, ns, ss, (long)m * ldp + n, nv);
+        const float4 mk4 = load4<VEC>(mask + (long)m * ldmask + n, nv);
+        const float z[4] = {v.x, v.y, v.z, v.w}, mk[4] = {mk4.x, mk4.y, mk4.z, mk4.w};
+        float h[4], d[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const float zz = z[k] + (k < nv ? bias[n + k] : 0.f);
+            const float lr = zz > 0.f ? zz : zz * slope;
+            h[k] = lr * mk[k];
+            d[k] = zz > 0.f ? mk[k] : mk[k] * slope;
+        }
+        store4<VEC>(H + (long)m * ldh + n, make_float4(h[0], h[1], h[2], h[3]), nv);
+        store4<VEC>(D + (long)m * ldd + n, make_float4(d[0], d[1], d[2], d[3]), nv);
     }
 }
 
@@ -79,21 +132,36 @@ __global__ void d_head_kernel(const float* __restrict__ H3, int ldh, const float
 
 // out = sumP * f(D) * colscale;  dmode: 0 no D, 1 multiply by D, 2 multiply by (D > 0), 3 ELU' from its output
 // (D > 0 ? 1 : D + 1).  Optional second copy out2 = out * rowscale[m].
+template <bool VEC>
 __global__ void ep_mul_kernel(const float* __restrict__ P, int ns, long ss, int ldp, int M, int N,
                               const float* __restrict__ D, int ldd, int dmode, const float* __restrict__ colscale,
                               const float* __restrict__ rowscale, float* __restrict__ out, float* __restrict__ out2,
                               int ldo) {
-    const int n = blockIdx.x * blockDim.x + threadIdx.x;
-    if (n >= N) return;
-    const float cs = colscale ? colscale[n] : 1.f;
-    for (int m = blockIdx.y; m < M; m += gridDim.y) {
-        float v = slab_sum(P, ns, ss, (long)m * ldp + n);
-        if (dmode == 1) v *= D[(long)m * ldd + n];
-        else if (dmode == 2) v = D[(long)m * ldd + n] > 0.f ? v : 0.f;
-        else if (dmode == 3) { const float y = D[(long)m * ldd + n]; v = y > 0.f ? v : v * (y + 1.f); }
-        v *= cs;
-        out[(long)m * ldo + n] = v;
-        if (out2) out2[(long)m * ldo + n] = v * rowscale[m];
+    const int n4 = (N + 3) >> 2;
+    const long total = (long)M * n4;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int m = (int)(i / n4), n = (int)(i - (long)m * n4) * 4, nv = min(4, N - n);
+        const float4 v4 = slab_sum4<VEC>(P, ns, ss, (long)m * ldp + n, nv);
+        float v[4] = {v4.x, v4.y, v4.z, v4.w};
+        if (dmode) {
+            const float4 d4 = load4<VEC>(D + (long)m * ldd + n, nv);
+            const float d[4] = {d4.x, d4.y, d4.z, d4.w};
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                if (dmode == 1) v[k] *= d[k];
+                else if (dmode == 2) v[k] = d[k] > 0.f ? v[k] : 0.f;
+                else v[k] = d[k] > 0.f ? v[k] : v[k] * (d[k] + 1.f);
+            }
+        }
+        if (colscale) {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) if (k < nv) v[k] *= colscale[n + k];
+        }
+        store4<VEC>(out + (long)m * ldo + n, make_float4(v[0], v[1], v[2], v[3]), nv);
+        if (out2) {
+            const float rs = rowscale[m];
+            store4<VEC>(out2 + (long)m * ldo + n, make_float4(v[0] * rs, v[1] * rs, v[2] * rs, v[3] * rs), nv);
+        }
     }
 }
 
@@ -127,14 +195,30 @@ __global__ void ep_penalty_row_kernel(const float* __restrict__ P, int ns, long 
     for (int j = threadIdx.x; j < S; j += blockDim.x) GH[(long)m * ldg + j] = coef * grow[j];
 }
 
-// out[n] (+)= sum_m X[m][n] * (rowscale ? rowscale[m] : 1)   (thread per column, coalesced)
+// Column-reduction kernels use 32 columns x 8 row groups per workgroup (coalesced 128-B row segments, LDS
+// reduce over the row groups) so that a 64..128-row batch still spreads over N/32 workgroups.
+constexpr int CT = 32, RG = 8;
+
+__device__ __forceinline__ float rg_reduce(float v, float (*red)[CT]) {
+    __syncthreads();
+    red[threadIdx.y][threadIdx.x] = v;
+    __syncthreads();
+    float r = 0.f;
+#pragma unroll
+    for (int g = 0; g < RG; ++g) r += red[g][threadIdx.x];
+    return r;
+}
+
+// out[n] (+)= sum_m X[m][n] * (rowscale ? rowscale[m] : 1)
 __global__ void colsum_kernel(const float* __restrict__ X, int ldx, int M, int N, const float* __restrict__ rowscale,
                               float* __restrict__ out, int accumulate) {
-    const int n = blockIdx.x * blockDim.x + threadIdx.x;
-    if (n >= N) return;
+    __shared__ float red[RG][CT];
+    const int n = blockIdx.x * CT + threadIdx.x;
     float a = 0.f;
-    for (int m = 0; m < M; ++m) a += X[(long)m * ldx + n] * (rowscale ? rowscale[m] : 1.f);
-    out[n] = accumulate ? out[n] + a : a;
+    if (n < N)
+        for (int m = threadIdx.y; m < M; m += RG) a += X[(long)m * ldx + n] * (rowscale ? rowscale[m] : 1.f);
+    a = rg_reduce(a, red);
+    if (n < N && threadIdx.y == 0) out[n] = accumulate ? out[n] + a : a;
 }
 
 // RMSprop (torch defaults: alpha .99, eps 1e-8, no momentum, not centered, wd 0), one flat pass
@@ -171,37 +255,30 @@ __global__ void rmsprop_kernel(float* __restrict__ p, const float* __restrict__ 
 // ---------------------------------------------------------------------------------------------------------
 // BatchNorm1d training forward, split so that data-parallel ranks can combine statistics between the halves.
 // stats kernel: Z = sumP + bias; per-column local mean and M2 = sum (z - mean)^2 (two passes, no cancellation).
-// blockDim = (64 columns, 4 row groups).
+// blockDim = (CT columns, RG row groups).
 __global__ void bn_stats_kernel(const float* __restrict__ P, int ns, long ss, int ldp, int M, int N,
                                 const float* __restrict__ bias, float* __restrict__ Z, int ldz,
                                 float* __restrict__ mean, float* __restrict__ m2) {
-    __shared__ float red[4][64];
-    const int n = blockIdx.x * 64 + threadIdx.x, rg = threadIdx.y;
+    __shared__ float red[RG][CT];
+    const int n = blockIdx.x * CT + threadIdx.x, rg = threadIdx.y;
     const bool ok = n < N;
     const float b = ok && bias ? bias[n] : 0.f;
     float s = 0.f;
     if (ok)
-        for (int m = rg; m < M; m += 4) {
+        for (int m = rg; m < M; m += RG) {
             const float z = slab_sum(P, ns, ss, (long)m * ldp + n) + b;
             Z[(long)m * ldz + n] = z;
             s += z;
         }
-    red[rg][threadIdx.x] = s;
-    __syncthreads();
-    const float mu = (red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x]) / (float)M;
-    __syncthreads();
+    const float mu = rg_reduce(s, red) / (float)M;
     float q = 0.f;
     if (ok)
-        for (int m = rg; m < M; m += 4) {
+        for (int m = rg; m < M; m += RG) {
             const float d = Z[(long)m * ldz + n] - mu;
             q = __fmaf_rn(d, d, q);
         }
-    red[rg][threadIdx.x] = q;
-    __syncthreads();
-    if (ok && rg == 0) {
-        mean[n] = mu;
-        m2[n] = red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x];
-    }
+    q = rg_reduce(q, red);
+    if (ok && rg == 0) { mean[n] = mu; m2[n] = q; }
 }
 
 // apply: var = m2 / count (biased); xhat = (z - mean) * rsqrt(var + eps); h = relu(gamma * xhat + beta).
@@ -263,33 +340,38 @@ __global__ void bn_bwd_kernel(const float* __restrict__ P, int ns, long ss, int 
                               const float* __restrict__ gamma, const float* __restrict__ invstd, float count,
                               float* __restrict__ sums, float* __restrict__ DZ, int lddz, float* __restrict__ dgamma,
                               float* __restrict__ dbeta, float* __restrict__ dbias, int phase) {
-    const int n = blockIdx.x * blockDim.x + threadIdx.x;
-    if (n >= N) return;
+    __shared__ float red[RG][CT];
+    const int n = blockIdx.x * CT + threadIdx.x, rg = threadIdx.y;
+    const bool ok = n < N;
+    float s0 = 0.f, s1 = 0.f;
     if (phase & 1) {
-        float s0 = 0.f, s1 = 0.f;
-        for (int m = 0; m < M; ++m) {
-            const long o = (long)m * ldh + n;
-            const float dy = H[o] > 0.f ? slab_sum(P, ns, ss, (long)m * ldp + n) : 0.f;
-            s0 += dy;
-            s1 = __fmaf_rn(dy, XH[o], s1);
-        }
-        sums[n] = s0;
-        sums[N + n] = s1;
+        // dy is parked in DZ between the two passes (each thread re-reads only what it wrote)
+        if (ok)
+            for (int m = rg; m < M; m += RG) {
+                const long o = (long)m * ldh + n;
+                const float dy = H[o] > 0.f ? slab_sum(P, ns, ss, (long)m * ldp + n) : 0.f;
+                DZ[(long)m * lddz + n] = dy;
+                s0 += dy;
+                s1 = __fmaf_rn(dy, XH[o], s1);
+            }
+        s0 = rg_reduce(s0, red);
+        s1 = rg_reduce(s1, red);
+        if (ok && rg == 0) { sums[n] = s0; sums[N + n] = s1; }
     }
     if (phase & 2) {
-        const float s0 = sums[n], s1 = sums[N + n];
-        const float k = gamma[n] * invstd[n], a0 = s0 / count, a1 = s1 / count;
+        if (!(phase & 1) && ok) { s0 = sums[n]; s1 = sums[N + n]; }
         float sb = 0.f;
-        for (int m = 0; m < M; ++m) {
-            const long o = (long)m * ldh + n;
-            const float dy = H[o] > 0.f ? slab_sum(P, ns, ss, (long)m * ldp + n) : 0.f;
-            const float dz = k * (dy - a0 - XH[o] * a1);
-            DZ[(long)m * lddz + n] = dz;
-            sb += dz;
+        if (ok) {
+            const float k = gamma[n] * invstd[n], a0 = s0 / count, a1 = s1 / count;
+            for (int m = rg; m < M; m += RG) {
+                const float dy = DZ[(long)m * lddz + n];
+                const float dz = k * (dy - a0 - XH[(long)m * ldh + n] * a1);
+                DZ[(long)m * lddz + n] = dz;
+                sb += dz;
+            }
         }
-        dgamma[n] = s1;
-        dbeta[n] = s0;
-        dbias[n] = sb;
+        sb = rg_reduce(sb, red);
+        if (ok && rg == 0) { dgamma[n] = s1; dbeta[n] = s0; dbias[n] = sb; }
     }
 }
 
@@ -323,21 +405,23 @@ __global__ void g_out_bwd_kernel(const float* __restrict__ P, int ns, long ss, i
                                  const float* __restrict__ dDF, int lddf, const float* __restrict__ fake, int ldf,
                                  const int* __restrict__ idx, float* __restrict__ DZ, int lddz,
                                  float* __restrict__ dbias) {
-    const int j = blockIdx.x * blockDim.x + threadIdx.x;
-    if (j >= S) return;
+    __shared__ float red[RG][CT];
+    const int j = blockIdx.x * CT + threadIdx.x;
     float sb = 0.f;
-    for (int m = 0; m < M; ++m) {
-        float dz = 0.f;
-        if (j < idx[m]) {
-            float df = dscale * slab_sum(P, ns, ss, (long)m * ldp + j);
-            if (dDF && j >= 1) df += dDF[(long)m * lddf + j - 1];
-            const float y = fake[(long)m * ldf + j];
-            dz = df * y * (1.f - y);
+    if (j < S)
+        for (int m = threadIdx.y; m < M; m += RG) {
+            float dz = 0.f;
+            if (j < idx[m]) {
+                float df = dscale * slab_sum(P, ns, ss, (long)m * ldp + j);
+                if (dDF && j >= 1) df += dDF[(long)m * lddf + j - 1];
+                const float y = fake[(long)m * ldf + j];
+                dz = df * y * (1.f - y);
+            }
+            DZ[(long)m * lddz + j] = dz;
+            sb += dz;
         }
-        DZ[(long)m * lddz + j] = dz;
-        sb += dz;
-    }
-    dbias[j] = sb;
+    sb = rg_reduce(sb, red);
+    if (j < S && threadIdx.y == 0) dbias[j] = sb;
 }
 
 // D-step scalars.  v rows [0,B) real, [B,2B) fake; pen rows likewise (W-div) or B interpolate rows (GP).
@@ -373,14 +457,26 @@ __global__ void g_head_kernel(const float* __restrict__ fv, int B, float invB, f
 
 // ---- internal launchers (used by step.hip) and their extern "C" faces -----------------------------------------
 static inline dim3 col_grid(int N, int M, int bx = 256) { return dim3(cdiv(N, bx), M < 64 ? M : 64); }
+static inline unsigned flat_grid(int M, int N) {
+    const long t = (long)M * ((N + 3) / 4);
+    long b = (t + 255) / 256;
+    if (b > 8192) b = 8192;
+    return (unsigned)(b < 1 ? 1 : b);
+}
+static inline bool al16(const void* p) { return p == nullptr || (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
 
 extern "C" {
 
 int wfd_ep_affine_act(const float* P, int ns, long ss, int ldp, int M, int N, const float* scale, const float* shift,
                       int act, float* out, int ldo, void* stream) {
     if (!P || !out || M <= 0 || N <= 0) return WFD_ERR_ARG;
-    hipLaunchKernelGGL(ep_affine_act_kernel, col_grid(N, M), dim3(256), 0, (hipStream_t)stream, P, ns, ss, ldp, M, N,
-                       scale, shift, act, out, ldo);
+    const bool vec = al16(P) && al16(out) && !(ldp & 3) && !(ldo & 3) && !(ss & 3) && !(N & 3);
+    if (vec)
+        hipLaunchKernelGGL(ep_affine_act_kernel<true>, dim3(flat_grid(M, N)), dim3(256), 0, (hipStream_t)stream, P, ns,
+                           ss, ldp, M, N, scale, shift, act, out, ldo);
+    else
+        hipLaunchKernelGGL(ep_affine_act_kernel<false>, dim3(flat_grid(M, N)), dim3(256), 0, (hipStream_t)stream, P, ns,
+                           ss, ldp, M, N, scale, shift, act, out, ldo);
     WFD_CHECK_LAUNCH();
     return WFD_OK;
 }
@@ -388,8 +484,14 @@ int wfd_ep_affine_act(const float* P, int ns, long ss, int ldp, int M, int N, co
 int wfd_ep_lrelu_drop(const float* P, int ns, long ss, int ldp, int M, int N, const float* bias, const float* mask,
                       int ldmask, float slope, float* H, int ldh, float* D, int ldd, void* stream) {
     if (!P || !bias || !mask || !H || !D) return WFD_ERR_ARG;
-    hipLaunchKernelGGL(ep_lrelu_drop_kernel, col_grid(N, M), dim3(256), 0, (hipStream_t)stream, P, ns, ss, ldp, M, N,
-                       bias, mask, ldmask, slope, H, ldh, D, ldd);
+    const bool vec = al16(P) && al16(mask) && al16(H) && al16(D) && !(ldp & 3) && !(ldmask & 3) && !(ldh & 3) &&
+                     !(ldd & 3) && !(ss & 3) && !(N & 3);
+    if (vec)
+        hipLaunchKernelGGL(ep_lrelu_drop_kernel<true>, dim3(flat_grid(M, N)), dim3(256), 0, (hipStream_t)stream, P, ns,
+                           ss, ldp, M, N, bias, mask, ldmask, slope, H, ldh, D, ldd);
+    else
+        hipLaunchKernelGGL(ep_lrelu_drop_kernel<false>, dim3(flat_grid(M, N)), dim3(256), 0, (hipStream_t)stream, P, ns,
+                           ss, ldp, M, N, bias, mask, ldmask, slope, H, ldh, D, ldd);
     WFD_CHECK_LAUNCH();
     return WFD_OK;
 }
@@ -407,8 +509,14 @@ int wfd_d_head(const float* H3, int ldh, const float* D3, int ldd, const float* 
 int wfd_ep_mul(const float* P, int ns, long ss, int ldp, int M, int N, const float* D, int ldd, int dmode,
                const float* colscale, const float* rowscale, float* out, float* out2, int ldo, void* stream) {
     if (!P || !out || (dmode && !D) || (out2 && !rowscale)) return WFD_ERR_ARG;
-    hipLaunchKernelGGL(ep_mul_kernel, col_grid(N, M), dim3(256), 0, (hipStream_t)stream, P, ns, ss, ldp, M, N, D, ldd,
-                       dmode, colscale, rowscale, out, out2, ldo);
+    const bool vec = al16(P) && al16(D) && al16(out) && al16(out2) && !(ldp & 3) && !(ldd & 3) && !(ldo & 3) &&
+                     !(ss & 3) && !(N & 3);
+    if (vec)
+        hipLaunchKernelGGL(ep_mul_kernel<true>, dim3(flat_grid(M, N)), dim3(256), 0, (hipStream_t)stream, P, ns, ss, ldp,
+                           M, N, D, ldd, dmode, colscale, rowscale, out, out2, ldo);
+    else
+        hipLaunchKernelGGL(ep_mul_kernel<false>, dim3(flat_grid(M, N)), dim3(256), 0, (hipStream_t)stream, P, ns, ss,
+                           ldp, M, N, D, ldd, dmode, colscale, rowscale, out, out2, ldo);
     WFD_CHECK_LAUNCH();
     return WFD_OK;
 }
@@ -425,8 +533,8 @@ int wfd_ep_penalty_row(const float* P, int ns, long ss, int ldp, int M, int S, i
 int wfd_colsum(const float* X, int ldx, int M, int N, const float* rowscale, float* out, int accumulate,
                void* stream) {
     if (!X || !out) return WFD_ERR_ARG;
-    hipLaunchKernelGGL(colsum_kernel, dim3(cdiv(N, 64)), dim3(64), 0, (hipStream_t)stream, X, ldx, M, N, rowscale, out,
-                       accumulate);
+    hipLaunchKernelGGL(colsum_kernel, dim3(cdiv(N, CT)), dim3(CT, RG), 0, (hipStream_t)stream, X, ldx, M, N, rowscale,
+                       out, accumulate);
     WFD_CHECK_LAUNCH();
     return WFD_OK;
 }
@@ -447,7 +555,7 @@ int wfd_rmsprop(float* p, const float* g, float* sq, long n, float lr, float alp
 int wfd_bn_stats(const float* P, int ns, long ss, int ldp, int M, int N, const float* bias, float* Z, int ldz,
                  float* mean, float* m2, void* stream) {
     if (!P || !Z || !mean || !m2) return WFD_ERR_ARG;
-    hipLaunchKernelGGL(bn_stats_kernel, dim3(cdiv(N, 64)), dim3(64, 4), 0, (hipStream_t)stream, P, ns, ss, ldp, M, N,
+    hipLaunchKernelGGL(bn_stats_kernel, dim3(cdiv(N, CT)), dim3(CT, RG), 0, (hipStream_t)stream, P, ns, ss, ldp, M, N,
                        bias, Z, ldz, mean, m2);
     WFD_CHECK_LAUNCH();
     return WFD_OK;
@@ -476,8 +584,8 @@ int wfd_bn_bwd(const float* P, int ns, long ss, int ldp, int M, int N, const flo
                const float* gamma, const float* invstd, float count, float* sums, float* DZ, int lddz, float* dgamma,
                float* dbeta, float* dbias, int phase, void* stream) {
     if (!P || !H || !XH || !gamma || !invstd || !sums) return WFD_ERR_ARG;
-    if ((phase & 2) && (!DZ || !dgamma || !dbeta || !dbias)) return WFD_ERR_ARG;
-    hipLaunchKernelGGL(bn_bwd_kernel, dim3(cdiv(N, 64)), dim3(64), 0, (hipStream_t)stream, P, ns, ss, ldp, M, N, H, XH,
+    if (!DZ || ((phase & 2) && (!dgamma || !dbeta || !dbias))) return WFD_ERR_ARG;
+    hipLaunchKernelGGL(bn_bwd_kernel, dim3(cdiv(N, CT)), dim3(CT, RG), 0, (hipStream_t)stream, P, ns, ss, ldp, M, N, H, XH,
                        ldh, gamma, invstd, count, sums, DZ, lddz, dgamma, dbeta, dbias, phase);
     WFD_CHECK_LAUNCH();
     return WFD_OK;
@@ -495,7 +603,7 @@ int wfd_ep_sigmoid_lenmask(const float* P, int ns, long ss, int ldp, int M, int 
 int wfd_g_out_bwd(const float* P, int ns, long ss, int ldp, int M, int S, float dscale, const float* dDF, int lddf,
                   const float* fake, int ldf, const int* idx, float* DZ, int lddz, float* dbias, void* stream) {
     if (!P || !fake || !idx || !DZ || !dbias) return WFD_ERR_ARG;
-    hipLaunchKernelGGL(g_out_bwd_kernel, dim3(cdiv(S, 64)), dim3(64), 0, (hipStream_t)stream, P, ns, ss, ldp, M, S,
+    hipLaunchKernelGGL(g_out_bwd_kernel, dim3(cdiv(S, CT)), dim3(CT, RG), 0, (hipStream_t)stream, P, ns, ss, ldp, M, S,
                        dscale, dDF, lddf, fake, ldf, idx, DZ, lddz, dbias);
     WFD_CHECK_LAUNCH();
     return WFD_OK;
