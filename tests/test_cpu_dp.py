@@ -1,0 +1,71 @@
+"""CPU, world_size 2 over gloo: the data-parallel path's collective logic.  Each rank computes oracle gradients on
+its own rows; allreduce_sum_ + the 1/world scale must reproduce the average of the per-rank gradients (DDP
+semantics), and replicas must stay identical after the optimizer step."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, q):
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), MASTER_ADDR="127.0.0.1",
+                      MASTER_PORT=str(port))
+    torch.set_num_threads(2)
+    from oracle import wfdgan_oracle as O
+    from wfd_gan_amd import parallel
+    r, w, _ = parallel.init_from_env(backend="gloo")
+    assert (r, w) == (rank, world)
+    S, C, Z, B = 41, 5, 16, 8
+    X, y = O.synth_dataset(C, 8, S - 1, 4, 13, 122, seed=3)
+    dmin, dmax = X.min(0), X.max(0)
+    scale, min_ = O.scaler_params(dmin, dmax)
+    Xs = torch.from_numpy(X * scale + min_)
+    a, b = parallel.shard_rows(2 * B, rank, world)            # this rank's rows of the global batch
+    st = O.make_state(S, C, Z, dmin[0], dmax[0], seed=1, df_seed=2)
+    g = torch.Generator().manual_seed(100 + rank)
+    z = torch.randn(b - a, Z, generator=g)
+    masks = [[(torch.rand(b - a, n, generator=g) > 0.2).float() * 1.25 for n in (2048, 1024, 512)] for _ in range(3)]
+    res = O.iteration(st, Xs[a:b], torch.from_numpy(y[a:b]), z, True, *masks, keep=True)
+    local = torch.cat([t.flatten() for t in res["d_grads"]])
+    flat = local.clone()
+    parallel.allreduce_sum_(flat)
+    flat /= world
+    gathered = [torch.zeros_like(local) for _ in range(world)]
+    dist.all_gather(gathered, local)
+    want = sum(gathered) / world
+    ok = torch.allclose(flat, want, rtol=0, atol=1e-7)
+    tmax = parallel.max_over_ranks(float(rank + 1), "cpu")
+    tsum = parallel.sum_over_ranks(1.0, "cpu")
+    t = torch.full((3,), float(rank))
+    parallel.broadcast_state_([t])
+    q.put((rank, bool(ok), tmax, tsum, t.tolist()))
+    dist.destroy_process_group()
+
+
+def test_gradient_allreduce_world2_gloo():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    out = [q.get(timeout=240) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for rank, ok, tmax, tsum, t in out:
+        assert ok, f"rank {rank}: all-reduced gradient != mean of per-rank gradients"
+        assert tmax == 2.0 and tsum == 2.0
+        assert t == [0.0, 0.0, 0.0]

@@ -1,0 +1,86 @@
+"""CPU: the oracle against the golden fixtures captured from the reference (tests/golden/make_golden.py)."""
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import wfdgan_oracle as O
+from tests.util import GOLDEN, load_iter_fixture, rebuild_state, unpack_masks
+
+
+@pytest.mark.parametrize("name", ["tiny", "cfg1"])
+def test_oracle_iteration_reproduces_reference_fixture(name):
+    torch.set_num_threads(8)
+    fx, meta = load_iter_fixture(name)
+    st = rebuild_state(meta, fx)
+    B = meta["batch"]
+    for it in range(meta["n_iter"]):
+        p = f"it{it}_"
+        do_g = it % meta["n_critic"] == 0
+        r = O.iteration(st, torch.from_numpy(fx[p + "traces"]).double(), torch.from_numpy(fx[p + "labels"]),
+                        torch.from_numpy(fx[p + "z"]), do_g, unpack_masks(fx, p + "mreal", B),
+                        unpack_masks(fx, p + "mfake", B), unpack_masks(fx, p + "mg", B), keep=True)
+        sc = fx[p + "scalars"]
+        # same machine class, same torch build: the fixture was asserted bit-exact at generation time; allow
+        # last-ulp drift across CPU models
+        for got, want in zip((r["d_loss"], r["penalty"], r["w_dist"], r["mean_rv"], r["mean_fv"]), sc):
+            assert abs(got - want) <= 2e-5 * abs(want) + 1e-7, (it, got, want)
+        assert np.allclose(r["n_r"].numpy(), fx[p + "n_r"], rtol=1e-4, atol=0)
+        assert np.array_equal(r["idx_d"].numpy(), fx[p + "idx_d"])
+        if do_g:
+            gs = fx[p + "g_scalars"]
+            assert abs(r["g_loss"] - gs[0]) <= 2e-5 * abs(gs[0]) + 1e-7
+            assert abs(r["f_loss"] - gs[1]) <= 2e-5 * abs(gs[1]) + 1e-7
+            assert r["n_sel"] == int(gs[3])
+
+
+def test_oracle_fp64_agrees_with_fp32_fixture():
+    """fp64 run of the same iteration: the fp32 reference numbers sit within fp32 noise of it, which bounds how
+    much of the 1e-3 GPU tolerance is the reference's own rounding."""
+    fx, meta = load_iter_fixture("tiny")
+    st = rebuild_state(meta, fx, dtype=torch.float64)
+    B = meta["batch"]
+    p = "it0_"
+    m = lambda k: [t.double() for t in unpack_masks(fx, p + k, B)]
+    r = O.iteration(st, torch.from_numpy(fx[p + "traces"]).double(), torch.from_numpy(fx[p + "labels"]),
+                    torch.from_numpy(fx[p + "z"]).double(), True, m("mreal"), m("mfake"), m("mg"))
+    sc = fx[p + "scalars"]
+    assert abs(r["d_loss"] - sc[0]) < 1e-5
+    assert abs(r["penalty"] - sc[1]) < 1e-4 * sc[1]
+
+
+@pytest.mark.parametrize("name", ["tiny", "cfg2"])
+def test_oracle_sampler_matches_reference_fixture(name):
+    fx = np.load(os.path.join(GOLDEN, f"sampler_{name}.npz"))
+    scale, min_ = O.scaler_params(fx["data_min"], fx["data_max"])
+    for i in range(fx["y"].shape[0]):
+        got = O.sample_postprocess(fx["y"][i], scale, min_)
+        want = fx["out"][i][: fx["out_len"][i]]
+        assert np.array_equal(got, want), i
+    for i in range(fx["adv_in"].shape[0]):
+        got = O.sample_postprocess(fx["adv_in"][i], scale, min_)
+        assert np.array_equal(got, fx["adv_out"][i][: fx["adv_len"][i]]), i
+
+
+def test_my_clip_matches_rowwise_definition():
+    rng = np.random.default_rng(0)
+    X = rng.integers(0, 700, size=(50, 41)).astype(np.float64)
+    got = O.my_clip(X, 550, 13, 122)
+    for r in range(X.shape[0]):
+        row = X[r].copy()
+        row[0] = min(row[0], 550)
+        for i in range(1, len(row), 2):
+            row[i] = min(row[i], 13)
+        for i in range(2, len(row), 2):
+            row[i] = min(row[i], 122)
+        assert np.array_equal(got[r], row)
+
+
+def test_generator_index_error_semantics():
+    """A saturated length output must raise IndexError as the reference's advanced-index assignment does."""
+    st = O.make_state(9, 2, 4, 0.0, 100.0, seed=0)
+    st.G["model.8.bias"].data[0] = 1e4         # sigmoid -> 1.0 exactly -> idx = S
+    with pytest.raises(IndexError):
+        O.g_forward(st.G, torch.zeros(3, 4), torch.eye(2)[[0, 1, 0]], 0.0, 8.0, training=True)
