@@ -67,9 +67,11 @@ int wfd_ep_mul(const float* P, int ns, long ss, int ldp, int M, int N, const flo
 
 /* Row-wise gradient penalty on g = sumP[m][0..S): nsq = ||g||^2;
  * mode 0 W-div (k=2,p=6): pen = nsq^3 (src/mlp_df_wgan_train.py:207,213); mode 1 WGAN-GP: pen = (||g||-1)^2
- * (src/utils.py:82-83).  GH = d(mean penalty)/dg, the seed of the double-backward (d_loss.backward(), :229). */
+ * (src/utils.py:82-83).  GH = d(mean penalty)/dg, the seed of the double-backward (d_loss.backward(), :229).
+ * rowflag (may be NULL): rows with flag 0 carry no penalty (pen = 0, GH = 0), e.g. the real / fake rows under
+ * WGAN-GP, where only the interpolates are penalised. */
 int wfd_ep_penalty_row(const float* P, int ns, long ss, int ldp, int M, int S, int mode, float invB, float lambda,
-                       float* nsq, float* pen, float* GH, int ldg, void* stream);
+                       const float* rowflag, float* nsq, float* pen, float* GH, int ldg, void* stream);
 
 /* out[n] (+)= sum_m X[m][n] * rowscale[m]  -- bias gradients (backward(), :229,:273) */
 int wfd_colsum(const float* X, int ldx, int M, int N, const float* rowscale, float* out, int accumulate,
@@ -150,6 +152,15 @@ int wfd_rng_dropout_mask(float* out, long n, float p, unsigned long long seed, c
 /* z ~ N(0,1) (np.random.normal, src/mlp_df_wgan_train.py:194; np.random.randn, src/generate.py:53) on device */
 int wfd_rng_normal_rows(float* out, int ld, int M, int Z, unsigned long long seed, const unsigned long long* state,
                         unsigned long long base, void* stream);
+
+/* U[0,1) interpolation weights (np.random.random((B,1)), src/utils.py:67) */
+int wfd_rng_uniform(float* out, long n, unsigned long long seed, const unsigned long long* state,
+                    unsigned long long base, void* stream);
+
+/* WGAN-GP interpolates alpha*real + (1-alpha)*fake on the first S columns, class columns [S,W) copied
+ * (src/utils.py:69) */
+int wfd_interpolate_rows(const float* real, const float* fake, const float* alpha, float* out, int B, int S, int W,
+                         int ld, void* stream);
 
 /* state[0] += inc0 (Philox counter), state[1] += inc1 (cursor into the epoch permutation) */
 int wfd_iter_advance(unsigned long long* state, unsigned long long inc0, unsigned long long inc1, void* stream);

@@ -17,7 +17,8 @@ What it does
      artefacts with oracle.train_loop.run_training under the same seeds,
   5. PIN D: reference-style sampling (generate.py:48-64 call sequence around the reference Generator and a real
      sklearn MinMaxScaler) == oracle.sample,
-  6. writes the fixtures (inputs, masks as packed bits, expected outputs).  Weights are NOT stored: tests
+  6. PIN E: the reference's utils.compute_gradient_penalty (WGAN-GP, src/utils.py:64-84) == oracle.wgan_gp_penalty,
+  7. writes the fixtures (inputs, masks as packed bits, expected outputs).  Weights are NOT stored: tests
      re-derive them from the seed with oracle.make_state and check the stored checksums.
 """
 import argparse
@@ -395,6 +396,44 @@ def pin_script_end_to_end():
     print("   wrote script_run.npz")
 
 
+def pin_gradient_penalty(ref_model):
+    """PIN E: the reference's own utils.compute_gradient_penalty (src/utils.py:64-84; its call site in the trainer
+    is commented out) vs oracle.wgan_gp_penalty with the same alpha / dropout masks, + a small fixture."""
+    print("[gp] reference utils.compute_gradient_penalty vs oracle")
+    import utils as ref_utils                      # /root/reference/src/utils.py
+    S, C, B = 41, 5, 8
+    torch.manual_seed(17)
+    D = ref_model.Discriminator(S, C)
+    dsd = {k: v.detach().clone() for k, v in D.state_dict().items()}
+    g = torch.Generator().manual_seed(3)
+    real, fake = torch.rand(B, S, generator=g), torch.rand(B, S, generator=g)
+    c = torch.eye(C)[torch.randint(0, C, (B,), generator=g)]
+    np.random.seed(99)
+    torch.manual_seed(5)
+    rng_state = torch.get_rng_state()
+    gp_ref = ref_utils.compute_gradient_penalty(D, real, fake, c, torch.FloatTensor)
+    np.random.seed(99)
+    alpha = torch.FloatTensor(np.random.random((B, 1)))
+    torch.set_rng_state(rng_state)
+    masks = O.draw_dropout_masks(B)
+    for p_ in dsd.values():
+        p_.requires_grad_(True)
+    gp_mine = O.wgan_gp_penalty(dsd, real, fake, c, alpha, masks)
+    assert float(gp_ref) == float(gp_mine), (float(gp_ref), float(gp_mine))
+    grads_ref = torch.autograd.grad(gp_ref, list(D.parameters()), allow_unused=True)
+    grads_mine = torch.autograd.grad(gp_mine, [dsd[k] for k in D.state_dict().keys()], allow_unused=True)
+    for a, b in zip(grads_ref, grads_mine):
+        if a is None:
+            assert b is None or float(b.abs().max()) == 0.0
+        else:
+            assert_same(a, b, "gp grad")
+    np.savez_compressed(os.path.join(HERE, "gp_tiny.npz"), real=real.numpy(), fake=fake.numpy(), c=c.numpy(),
+                        alpha=alpha.numpy(), gp=float(gp_ref), d_seed=17,
+                        **{f"m{i}": pk for i, pk in enumerate(pack_masks(masks))},
+                        grad_norms=np.array([0.0 if a is None else float(a.double().norm()) for a in grads_ref]))
+    print(f"   gp = {float(gp_ref):.6f}: bit-exact incl. parameter gradients; wrote gp_tiny.npz")
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--skip-script", action="store_true")
@@ -413,6 +452,8 @@ def main():
     if not args.only or args.only == "sampler":
         make_sampler_case(ref_model, "cfg2", 1401, 100, 500, 100, seed=31)
         make_sampler_case(ref_model, "tiny", 41, 5, 16, 50, seed=32)
+    if not args.only or args.only == "gp":
+        pin_gradient_penalty(ref_model)
     if not args.skip_script and (not args.only or args.only == "script"):
         pin_script_end_to_end()
     print("ALL PINS PASSED")

@@ -1,0 +1,168 @@
+"""GPU: WGAN-GP penalty mode vs the oracle (pinned against the reference's utils.compute_gradient_penalty by
+tests/golden/make_golden.py), the fast (device RNG + HIP graph) path, and the trainer / sampler CLIs end to end."""
+import glob
+import json
+import os
+import re
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import wfdgan_oracle as O
+from tests.util import rel_err
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+def _setup(S, C, Z, B, penalty, seed=1):
+    from wfd_gan_amd.engine import TrainEngine
+    X, y = O.synth_dataset(C, max(8, 4 * B // C + 1), S - 1, max(2, S // 10), 13, 122, seed=3)
+    dmin, dmax = X.min(0), X.max(0)
+    scale, min_ = O.scaler_params(dmin, dmax)
+    Xs = X * scale + min_
+    st = O.make_state(S, C, Z, dmin[0], dmax[0], seed=seed, df_seed=seed + 1, penalty=penalty)
+    eng = TrainEngine(S, C, Z, B, dmin[0], dmax[0], {k: v.detach() for k, v in st.G.items()},
+                      {k: v.detach() for k, v in st.D.items()}, st.DF, penalty=penalty, device=DEV)
+    return st, eng, Xs, y
+
+
+@pytest.mark.parametrize("cfg", [(41, 5, 16, 8), (501, 10, 500, 64)])
+def test_wgan_gp_mode_matches_oracle(cfg):
+    S, C, Z, B = cfg
+    st, eng, Xs, y = _setup(S, C, Z, B, "gp")
+    g = torch.Generator().manual_seed(0)
+    perm = torch.randperm(Xs.shape[0], generator=g)
+    for it in range(4):
+        idx = perm[it * B:(it + 1) * B].numpy()
+        traces, labels = torch.from_numpy(Xs[idx]), torch.from_numpy(y[idx])
+        z = torch.randn(B, Z, generator=g)
+        alpha = torch.rand(B, 1, generator=g)
+        mk = lambda: [(torch.rand(B, n, generator=g) > 0.2).float() * 1.25 for n in (2048, 1024, 512)]
+        mr, mf, mgp, mg = mk(), mk(), mk(), mk()
+        do_g = it % 3 == 0
+        ref = O.iteration(st, traces, labels, z, do_g, mr, mf, mg, gp_alpha=alpha, masks_gp=mgp, keep=True)
+        eng.set_batch(traces, labels, z)
+        eng.set_gp_alpha(alpha)
+        eng.set_masks([torch.cat([a, b, c]) for a, b, c in zip(mr, mf, mgp)], mg)
+        eng.d_step()
+        if do_g:
+            eng.g_step()
+        torch.cuda.synchronize()
+        d = eng.d_stats()
+        assert abs(d["penalty"] - ref["penalty"]) <= 1e-3 * abs(ref["penalty"]), (it, d["penalty"], ref["penalty"])
+        assert abs(d["d_loss"] - ref["d_loss"]) <= 1e-3 * abs(ref["d_loss"]) + 4e-5, (it, d["d_loss"], ref["d_loss"])
+        assert abs(d["w_dist"] - ref["w_dist"]) <= 1e-3 * abs(ref["w_dist"]) + 4e-5
+        # critic gradients of this iteration (norm per tensor) -- the grad buffer still holds them
+        for (name, _), gref in zip(eng.Dp.specs, ref["d_grads"]):
+            got = eng.Dp.g[name].cpu()
+            nref = float(gref.double().norm())
+            assert float((got.double() - gref.double()).norm()) <= 1e-3 * nref + 1e-7, (it, name)
+        if do_g:
+            gs = eng.g_stats()
+            assert abs(gs["g_loss"] - ref["g_loss"]) <= 1e-3 * abs(ref["g_loss"]) + 2e-5
+            assert gs["n_sel"] == ref["n_sel"]
+
+
+def test_wdiv_gradients_match_oracle_per_tensor():
+    """every critic / generator gradient tensor of one iteration vs autograd (oracle), relative L2 error."""
+    S, C, Z, B = 501, 10, 64, 32
+    st, eng, Xs, y = _setup(S, C, Z, B, "div", seed=4)
+    g = torch.Generator().manual_seed(1)
+    traces, labels = torch.from_numpy(Xs[:B]), torch.from_numpy(y[:B].copy())
+    z = torch.randn(B, Z, generator=g)
+    mk = lambda: [(torch.rand(B, n, generator=g) > 0.2).float() * 1.25 for n in (2048, 1024, 512)]
+    mr, mf, mg = mk(), mk(), mk()
+    # make the critic like some fakes so that the observer term is exercised
+    with torch.no_grad():
+        st.D["model.9.bias"] += 0.3
+        eng.Dp.p["model.9.bias"] += 0.3
+    ref = O.iteration(st, traces, labels, z, True, mr, mf, mg, keep=True)
+    eng.set_batch(traces, labels, z)
+    eng.set_masks([torch.cat([a, b]) for a, b in zip(mr, mf)], mg)
+    eng.d_step()
+    torch.cuda.synchronize()
+    for (name, _), gref in zip(eng.Dp.specs, ref["d_grads"]):
+        got = eng.Dp.g[name].cpu().double()
+        assert float((got - gref.double()).norm()) <= 1e-3 * float(gref.double().norm()) + 1e-7, name
+    eng.g_step()
+    torch.cuda.synchronize()
+    assert ref["n_sel"] > 0 and eng.g_stats()["n_sel"] == ref["n_sel"]
+    assert abs(eng.g_stats()["f_loss"] - ref["f_loss"]) <= 1e-3 * ref["f_loss"]
+    for (name, _), gref in zip(eng.Gp.specs, ref["g_grads"]):
+        got = eng.Gp.g[name].cpu().double()
+        nref = float(gref.double().norm())
+        if name in ("model.2.bias", "model.5.bias"):
+            # bias in front of BatchNorm: its true gradient is 0; both sides hold rounding noise only
+            assert float(got.norm()) < 1e-5 and nref < 1e-5
+            continue
+        assert float((got - gref.double()).norm()) <= 1e-3 * nref + 1e-7, name
+
+
+def test_fast_mode_graph_equals_eager():
+    """device RNG + gather + HIP-graph replay reproduces the eager launches bit for bit (same Philox counters)."""
+    from wfd_gan_amd.engine import TrainEngine
+    S, C, Z, B = 41, 5, 16, 8
+    st, e1, Xs, y = _setup(S, C, Z, B, "div")
+    _, e2, _, _ = _setup(S, C, Z, B, "div")
+    for e in (e1, e2):
+        e.attach_dataset(torch.from_numpy(Xs), torch.from_numpy(y), shuffle_seed=5)
+    e2.capture_graphs()
+    for i in range(7):
+        e1.iteration(i)
+        e2.iteration(i)
+    torch.cuda.synchronize()
+    assert torch.equal(e1.Dp.flat, e2.Dp.flat) and torch.equal(e1.Gp.flat, e2.Gp.flat)
+    assert torch.equal(e1.iter_state, e2.iter_state)
+    assert e1.d_stats() == e2.d_stats()
+    assert torch.isfinite(e1.Dp.flat).all() and torch.isfinite(e1.Gp.flat).all()
+
+
+def test_trainer_and_sampler_cli(tmp_path):
+    from wfd_gan_amd import generate, mlp_df_wgan_train
+    n_cls, n_inst, L = 5, 21, 40           # 105 rows, batch 16 -> 6 full batches + ragged tail of 9
+    X, y = O.synth_dataset(n_cls, n_inst, L, 4, 13, 122, seed=0)
+    ddir = tmp_path / "ds" / "feature"
+    ddir.mkdir(parents=True)
+    npz = str(ddir / "raw_feature_synth.npz")
+    np.savez(npz, features=X, labels=y + 3)          # labels not starting at 0: the trainer re-indexes (:130)
+    torch.manual_seed(0)
+    ck = str(tmp_path / "df.ckpt")
+    torch.save(O.make_df_state(L, n_cls), ck)
+    out = mlp_df_wgan_train.main(["-d", npz, "--f_model", ck, "--n_epochs", "2", "--batch_size", "16",
+                                  "--latent_dim", "24", "--seed", "7", "--freq", "2"])
+    assert os.path.isfile(os.path.join(out, "args.json")) and os.path.isfile(os.path.join(out, "log.txt"))
+    log = open(os.path.join(out, "log.txt")).read()
+    assert len(re.findall(r"\[Epoch +\d+/ *2\] \[D loss: ", log)) == 2
+    for ep in (1, 2):
+        d = np.load(os.path.join(out, "checkpoint", f"epoch_{ep}.npz"))
+        assert d["x"].dtype == np.float64 and d["recon_x"].dtype == np.float32 and d["label"].dtype == np.int64
+        assert d["x"].shape == d["recon_x"].shape and d["x"].shape[1] == L + 1
+        # 7 batches per epoch, G-steps at i = 0, 3, 6 -> 16 + 16 + 9 rows
+        assert d["x"].shape[0] == 41
+        assert np.allclose(d["x"], np.round(d["x"]))          # inverse-transformed real rows are the integer data
+    ls = np.load(os.path.join(out, "checkpoint", "loss.npz"))
+    assert all(len(ls[k]) == 2 for k in ("generator", "discriminator", "dist"))
+    assert np.isfinite(ls["discriminator"]).all()
+    gck = glob.glob(os.path.join(out, "model", "generator_seqlen41_cls5_latentdim24.ckpt"))
+    assert len(gck) == 1
+    gsd = torch.load(gck[0], weights_only=True)
+    assert list(gsd.keys()) == list(O.make_generator_state(41, 5, 24).keys())
+    assert int(gsd["model.3.num_batches_tracked"]) == 2 * (7 + 3)
+    dsd = torch.load(os.path.join(out, "model", "discriminator.ckpt"), weights_only=True)
+    assert list(dsd.keys()) == list(O.make_discriminator_state(41, 5).keys())
+    assert os.path.isfile(os.path.join(out, "model", "scaler.gz"))
+    # sampler on the artefacts: CLI + sample(c_ind) vs the oracle's sample() on the same z
+    ts = generate.TraceSampler(os.path.join(out, "model"), device=DEV, chunk=64)
+    outs, lens = ts.sample_many(torch.arange(100) % 5)
+    assert outs.shape == (100, 41) and int(lens.min()) >= 1
+    assert bool((outs[torch.arange(41)[None, :].to(DEV) < lens[:, None]] > 0).all())
+    zr = np.random.RandomState(0).randn(1, 24).astype("float32")
+    mine = ts.sample(2, zr)
+    scale, min_ = O.scaler_params(ts.scaler.data_min_, ts.scaler.data_max_)
+    want = O.sample({k: v for k, v in gsd.items()}, 2, zr, 5, ts.scaler.data_min_[0], ts.scaler.data_max_[0], scale, min_)
+    assert len(mine) == len(want) and np.abs(mine - want).max() <= 1
+    generate.main(["-m", os.path.join(out, "model"), "--n", "300", "--chunk", "128", "--out", str(tmp_path / "t.npz")])
+    t = np.load(str(tmp_path / "t.npz"))
+    assert t["traces"].shape == (300, 41) and t["lens"].shape == (300,)

@@ -170,7 +170,8 @@ __global__ void ep_mul_kernel(const float* __restrict__ P, int ns, long ss, int 
 //   mode 1 (WGAN-GP):          pen[m] = (sqrt(n) - 1)^2,  seed = 2 lambda invB (sqrt(n)-1)/sqrt(n) * g
 // seed (= d loss / d g) is written to GH[m][0..S).  One workgroup per row.
 __global__ void ep_penalty_row_kernel(const float* __restrict__ P, int ns, long ss, int ldp, int S, int mode,
-                                      float invB, float lambda, float* __restrict__ nsq, float* __restrict__ pen,
+                                      float invB, float lambda, const float* __restrict__ rowflag,
+                                      float* __restrict__ nsq, float* __restrict__ pen,
                                       float* __restrict__ GH, int ldg) {
     __shared__ float red[16];
     extern __shared__ float grow[];
@@ -191,6 +192,7 @@ __global__ void ep_penalty_row_kernel(const float* __restrict__ P, int ns, long 
         pv = (nr - 1.f) * (nr - 1.f);
         coef = nr > 0.f ? 2.f * lambda * invB * (nr - 1.f) / nr : 0.f;
     }
+    if (rowflag && rowflag[m] == 0.f) { coef = 0.f; pv = 0.f; }     // row carries no penalty term
     if (threadIdx.x == 0) { nsq[m] = n; pen[m] = pv; }
     for (int j = threadIdx.x; j < S; j += blockDim.x) GH[(long)m * ldg + j] = coef * grow[j];
 }
@@ -522,10 +524,10 @@ int wfd_ep_mul(const float* P, int ns, long ss, int ldp, int M, int N, const flo
 }
 
 int wfd_ep_penalty_row(const float* P, int ns, long ss, int ldp, int M, int S, int mode, float invB, float lambda,
-                       float* nsq, float* pen, float* GH, int ldg, void* stream) {
+                       const float* rowflag, float* nsq, float* pen, float* GH, int ldg, void* stream) {
     if (!P || !nsq || !pen || !GH || S <= 0 || (size_t)S * 4 > 60000) return WFD_ERR_ARG;
     hipLaunchKernelGGL(ep_penalty_row_kernel, dim3(M), dim3(256), (size_t)S * sizeof(float), (hipStream_t)stream, P, ns,
-                       ss, ldp, S, mode, invB, lambda, nsq, pen, GH, ldg);
+                       ss, ldp, S, mode, invB, lambda, rowflag, nsq, pen, GH, ldg);
     WFD_CHECK_LAUNCH();
     return WFD_OK;
 }

@@ -80,6 +80,35 @@ __global__ void gather_batch_kernel(const float* __restrict__ X, int ldX, const 
     if (threadIdx.x == 0 && labels_out) labels_out[b] = lab;
 }
 
+// U[0,1) row weights (np.random.random((B,1)), src/utils.py:67)
+__global__ void rng_uniform_kernel(float* __restrict__ out, long n, unsigned long long seed,
+                                   const unsigned long long* __restrict__ state, unsigned long long base) {
+    const unsigned long long offset = (state ? state[0] : 0ull) + base;
+    const long stride = (long)gridDim.x * blockDim.x;
+    for (long q = (long)blockIdx.x * blockDim.x + threadIdx.x; q * 4 < n; q += stride) {
+        const unsigned long long c = offset + (unsigned long long)q;
+        const uint4 r = philox4x32_10(make_uint4((uint32_t)c, (uint32_t)(c >> 32), 0x756e6966u, 0u),
+                                      make_uint2((uint32_t)seed, (uint32_t)(seed >> 32)));
+        const float v[4] = {(r.x >> 8) * (1.0f / 16777216.0f), (r.y >> 8) * (1.0f / 16777216.0f),
+                            (r.z >> 8) * (1.0f / 16777216.0f), (r.w >> 8) * (1.0f / 16777216.0f)};
+        for (int k = 0; k < 4; ++k)
+            if (q * 4 + k < n) out[q * 4 + k] = v[k];
+    }
+}
+
+// WGAN-GP interpolates (src/utils.py:69): out[b][j] = a_b * real[b][j] + ((1 - a_b) * fake[b][j]) for j < S,
+// class columns j in [S, W) copied from real.  Separate roundings, as the tensor expression evaluates.
+__global__ void interpolate_rows_kernel(const float* __restrict__ real, const float* __restrict__ fake,
+                                        const float* __restrict__ alpha, float* __restrict__ out, int S, int W,
+                                        int ld) {
+    const int b = blockIdx.x;
+    const float a = alpha[b], na = __fsub_rn(1.0f, a);
+    for (int j = threadIdx.x; j < W; j += blockDim.x) {
+        const long o = (long)b * ld + j;
+        out[o] = j < S ? __fadd_rn(__fmul_rn(a, real[o]), __fmul_rn(na, fake[o])) : real[o];
+    }
+}
+
 // per-iteration device state: state[0] = Philox counter offset, state[1] = cursor into the epoch permutation
 __global__ void iter_advance_kernel(unsigned long long* __restrict__ state, unsigned long long inc0,
                                     unsigned long long inc1) {
@@ -173,6 +202,27 @@ int wfd_gather_batch(const float* X, int ldX, const int* y, const long long* idx
     if (!X || !y || !idx || !real || B <= 0) return WFD_ERR_ARG;
     hipLaunchKernelGGL(gather_batch_kernel, dim3(B), dim3(256), 0, (hipStream_t)stream, X, ldX, y, idx, state, S, C, real,
                        fake, ldd, zin, ldz, Z, labels_out);
+    WFD_CHECK_LAUNCH();
+    return WFD_OK;
+}
+
+int wfd_rng_uniform(float* out, long n, unsigned long long seed, const unsigned long long* state,
+                    unsigned long long base, void* stream) {
+    if (!out || n <= 0) return WFD_ERR_ARG;
+    long blocks = (n / 4 + 255) / 256;
+    if (blocks > 2048) blocks = 2048;
+    if (blocks < 1) blocks = 1;
+    hipLaunchKernelGGL(rng_uniform_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, out, n, seed,
+                       state, base);
+    WFD_CHECK_LAUNCH();
+    return WFD_OK;
+}
+
+int wfd_interpolate_rows(const float* real, const float* fake, const float* alpha, float* out, int B, int S, int W,
+                         int ld, void* stream) {
+    if (!real || !fake || !alpha || !out || B <= 0 || W < S || ld < W) return WFD_ERR_ARG;
+    hipLaunchKernelGGL(interpolate_rows_kernel, dim3(B), dim3(256), 0, (hipStream_t)stream, real, fake, alpha, out, S,
+                       W, ld);
     WFD_CHECK_LAUNCH();
     return WFD_OK;
 }

@@ -155,7 +155,8 @@ class TrainEngine:
                  scaler_max: float, G_state: Dict[str, torch.Tensor], D_state: Dict[str, torch.Tensor],
                  DF_state: Dict[str, torch.Tensor], lr: float = 2e-4, alpha: float = 0.02, n_critic: int = 3,
                  penalty: str = "div", lambda_gp: float = 10.0, device="cuda:0", global_batch: Optional[int] = None,
-                 seed: int = 0, workspace_mb: int = 256, process_group=None, world_size: int = 1):
+                 seed: int = 0, workspace_mb: int = 256, process_group=None, world_size: int = 1,
+                 share: Optional["TrainEngine"] = None):
         if not torch.cuda.is_available():
             raise RuntimeError("wfd_gan_amd.TrainEngine needs a HIP device: there is no CPU path")
         if penalty not in ("div", "gp"):
@@ -180,15 +181,20 @@ class TrainEngine:
         dev = self.dev
         f32 = dict(dtype=torch.float32, device=dev)
 
-        self.Gp = FlatParams(G_PARAM_SPECS(S, C, Z), dev)
-        self.Dp = FlatParams(D_PARAM_SPECS(S, C), dev)
-        self.Gp.load(G_state)
-        self.Dp.load(D_state)
-        self.Gbuf = {k: G_state[k].detach().to(**f32).clone() for k in G_BUFFER_KEYS}
-        for k in self.nbt:
-            if f"{k}.num_batches_tracked" in G_state:
-                self.nbt[k] = int(G_state[f"{k}.num_batches_tracked"])
-        self.df = ObserverDF(DF_state, S - 1, C, dev)
+        if share is not None:
+            # a second engine for another batch size (the ragged last batch of an epoch) on the SAME parameters,
+            # optimizer state, BN buffers and packed observer
+            self.Gp, self.Dp, self.Gbuf, self.nbt, self.df = share.Gp, share.Dp, share.Gbuf, share.nbt, share.df
+        else:
+            self.Gp = FlatParams(G_PARAM_SPECS(S, C, Z), dev)
+            self.Dp = FlatParams(D_PARAM_SPECS(S, C), dev)
+            self.Gp.load(G_state)
+            self.Dp.load(D_state)
+            self.Gbuf = {k: G_state[k].detach().to(**f32).clone() for k in G_BUFFER_KEYS}
+            for k in self.nbt:
+                if f"{k}.num_batches_tracked" in G_state:
+                    self.nbt[k] = int(G_state[f"{k}.num_batches_tracked"])
+            self.df = ObserverDF(DF_state, S - 1, C, dev)
 
         # ---- activations -------------------------------------------------------------------------------
         self.nside = 2 if penalty == "div" else 3     # row groups per D-step: real, fake (, interpolates)
@@ -209,8 +215,10 @@ class TrainEngine:
         b["T2H2"] = z(2 * M, 1024)       # [t_2 ; h_2]
         b["H3"], b["T3"] = z(M, 512), z(M, 512)
         b["V"], b["NSQ"], b["PEN"], b["DV"], b["PENFLAG"] = z(M), z(M), z(M), z(M), z(M)
-        b["dstats"], b["dacc"] = z(8), z(4)
-        b["gstats"], b["gacc"], b["ghead"] = z(8), z(4), z(2)
+        b["GPA"] = z(B)                  # WGAN-GP interpolation weights alpha (B,1)
+        b["dstats"], b["gstats"], b["ghead"] = z(8), z(8), z(2)
+        b["dacc"] = share.buf["dacc"] if share is not None else z(4)      # epoch sums live on device
+        b["gacc"] = share.buf["gacc"] if share is not None else z(4)
         # generator
         b["GH1"] = z(B, 512)
         for i, n in ((2, 1024), (3, 2048)):
@@ -323,7 +331,9 @@ class TrainEngine:
         p = Plan(b["ws"])
         self._g_forward(p, nupd=1)
         if self.penalty == "gp":
-            raise NotImplementedError  # filled in by _gp_interpolate below when enabled
+            # interpolates = third row group of the critic input (src/utils.py:67-69)
+            p.add(self.L.interpolate_rows, ptr(self.real_rows), ptr(self.fake_rows), ptr(b["GPA"]),
+                  ptr(self.din[2 * B:]), B, S, S + C, self.ldx)
         din = self.din
         H1, H2 = b["T1H1"][M:], b["T2H2"][M:]
         self._critic_forward(p, din, M, (b["MK1"], b["MK2"], b["MK3"]), H1, H2, b["H3"], b["D1"], b["D2"], b["D3"],
@@ -332,8 +342,9 @@ class TrainEngine:
                                b["D1"], b["DV"])
         mode = 0 if self.penalty == "div" else 1
         p.add(self.L.ep_penalty_row, g.ptr, g.ns, g.ss, g.ldp, M, S, mode, 1.0 / self.Bg, self.lambda_gp,
-              ptr(b["NSQ"]), ptr(b["PEN"]), ptr(b["XC"]), self.ldx)
-        p.add(self.L.d_loss, ptr(b["V"]), ptr(b["PEN"]), B, M, 1.0 / self.Bg, 1.0, ptr(b["dstats"]), ptr(b["dacc"]))
+              ptr(b["PENFLAG"]), ptr(b["NSQ"]), ptr(b["PEN"]), ptr(b["XC"]), self.ldx)
+        p.add(self.L.d_loss, ptr(b["V"]), ptr(b["PEN"]), B, M, 1.0 / self.Bg,
+              1.0 if self.penalty == "div" else self.lambda_gp, ptr(b["dstats"]), ptr(b["dacc"]))
         # t-chain (second-order part of d_loss.backward())
         Dp = D.p
         s = p.gemm(NT, b["XC"], self.ldx, Dp["model.0.weight"], S + C, M, 2048, S)
@@ -469,18 +480,23 @@ class TrainEngine:
             for i, m in enumerate(g_masks):
                 self.buf[f"gMK{i + 1}"].copy_(m.to(self.dev, torch.float32))
 
+    def set_gp_alpha(self, alpha: torch.Tensor):
+        """Explicit WGAN-GP interpolation weights (B,1) or (B,) (parity mode)."""
+        self.buf["GPA"].copy_(alpha.reshape(-1).to(self.dev, torch.float32))
+
     def draw_masks(self, g_step: bool):
         """Fast mode: Philox keep-masks on device (one launch per mask tensor)."""
         st = torch.cuda.current_stream().cuda_stream
         names = ["MK1", "MK2", "MK3"] + (["gMK1", "gMK2", "gMK3"] if g_step else [])
-        for nme in names:
+        for k, nme in enumerate(names):
             t = self.buf[nme]
-            self.L.rng_dropout_mask(t.data_ptr(), t.numel(), 0.2, self.seed, self.rng_offset, st)
-            self.rng_offset += (t.numel() + 3) // 4
+            self.L.rng_dropout_mask(t.data_ptr(), t.numel(), 0.2, (self.seed + 31 * (k + 1)) & (2**64 - 1), 0,
+                                    self.rng_offset, st)
+        self.rng_offset += (self.buf["MK1"].numel() + 3) // 4
 
     def draw_z(self):
         st = torch.cuda.current_stream().cuda_stream
-        self.L.rng_normal_rows(self.buf["ZIN"].data_ptr(), self.ldz, self.B, self.Z, self.seed ^ 0x5A5A5A5A,
+        self.L.rng_normal_rows(self.buf["ZIN"].data_ptr(), self.ldz, self.B, self.Z, self.seed ^ 0x5A5A5A5A, 0,
                                self.rng_offset, st)
         self.rng_offset += (self.B * self.Z + 3) // 4
 
@@ -554,6 +570,8 @@ class TrainEngine:
             t = b[nme]
             pd.add(self.L.rng_dropout_mask, ptr(t), t.numel(), 0.2, (self.seed + (k + 1) * gold) & (2**64 - 1), st, 0)
             inc = max(inc, (t.numel() + 3) // 4)
+        if self.penalty == "gp":
+            pd.add(self.L.rng_uniform, ptr(b["GPA"]), B, (self.seed + 11 * gold) & (2**64 - 1), st, 0)
         pd.calls += self.plan_d.calls
         pd.add(self.L.iter_advance, st, inc, B)
         pg = Plan(b["ws"])

@@ -1,0 +1,205 @@
+#!/usr/bin/env python3
+"""cGAN + DF-observer trainer on the MI355X kernels: same CLI, npz input and output files as the reference's
+src/mlp_df_wgan_train.py (flags :38-54, artefacts :104-112,286-313).
+
+    python -m wfd_gan_amd.mlp_df_wgan_train -d <...>/feature/raw_feature_x.npz --f_model df.ckpt [--n_epochs 800 ...]
+
+Additive flags (defaults reproduce the reference): --penalty {div,gp}, --seed, --no_graph.
+Per iteration nothing leaves the GPU: the dataset is resident in HBM, batches / z / dropout masks are produced on
+device, the D-step and G-step are HIP-graph replays, and the epoch's loss sums accumulate in device memory (the
+reference's 2-5 ``.item()`` syncs and per-G-step D2H copies are gone; one sync per epoch reads the sums).
+"""
+import argparse
+import json
+import os
+from os.path import join
+from time import strftime
+
+import joblib
+import numpy as np
+import torch
+from sklearn import preprocessing
+
+from . import common as cm
+from . import utils
+from ._lib import lib
+from .engine import TrainEngine
+from .model import DF, Discriminator, Generator
+
+w_dist_threshold = 0.05          # src/mlp_df_wgan_train.py:24
+
+# --clip caps (walkie-talkie values the reference ships, :34-36)
+MAX_BURST_LENGTH = 550
+MAX_OUTGOING_SIZE = 13
+MAX_INCOMING_SIZE = 122
+
+
+def parse_args(argv=None):
+    p = argparse.ArgumentParser()
+    p.add_argument("-d", "--dir", required=True, help="Dataset directory.")
+    p.add_argument("--clip", action="store_true", default=False,
+                   help="Whether to clip the burst size of the dataset before training")
+    p.add_argument("--f_model", type=str, required=True, help="The directory of the pre-trained DF.")
+    p.add_argument("--n_epochs", type=int, default=800, help="number of epochs of training")
+    p.add_argument("--batch_size", type=int, default=64, help="size of the batches")
+    p.add_argument("--lr", type=float, default=0.0002, help="learning rate")
+    p.add_argument("--n_cpu", type=int, default=2, help="kept for CLI compatibility; batches are built on the GPU")
+    p.add_argument("--latent_dim", type=int, default=500, help="dimensionality of the latent space")
+    p.add_argument("--n_critic", type=int, default=3, help="number of training steps for discriminator per iter")
+    p.add_argument("--alpha", type=float, default=0.02, help="Max ratio of f loss")
+    p.add_argument("--freq", type=int, default=20, help="Checkpoint every freq epochs")
+    p.add_argument("--cuda_id", type=int, default=0, help="GPU ID")
+    # additive
+    p.add_argument("--penalty", choices=["div", "gp"], default="div",
+                   help="div = W-div (what the reference runs); gp = interpolated WGAN-GP (utils.py:64-84)")
+    p.add_argument("--seed", type=int, default=None, help="seed for init / shuffling / device RNG")
+    p.add_argument("--no_graph", action="store_true", help="launch kernels eagerly instead of HIP-graph replay")
+    return p.parse_args(argv)
+
+
+def clip_dataset(X: np.ndarray, device) -> np.ndarray:
+    """--clip on the device (float64, in place), then the reference's sanity asserts (:122-125)."""
+    Xd = torch.from_numpy(np.ascontiguousarray(X, dtype=np.float64)).to(device)
+    lib().clip_bursts(Xd.data_ptr(), Xd.shape[0], Xd.shape[1], float(MAX_BURST_LENGTH), float(MAX_OUTGOING_SIZE),
+                      float(MAX_INCOMING_SIZE), torch.cuda.current_stream().cuda_stream)
+    X = Xd.cpu().numpy()
+    assert X[:, 0].max() == MAX_BURST_LENGTH
+    assert X[:, 1::2].max() == MAX_OUTGOING_SIZE
+    assert X[:, 2::2].max() == MAX_INCOMING_SIZE
+    return X
+
+
+def df_accuracy(f_model: DF, fakes: torch.Tensor, labels: torch.Tensor) -> float:
+    """test_DF_acc_epoch (:57-79): DF argmax accuracy over this epoch's generated traces, batches of 128."""
+    total, correct = 0, 0
+    for a in range(0, fakes.shape[0], 128):
+        x = fakes[a:a + 128, 1:]
+        pred = f_model(x.reshape(x.shape[0], 1, x.shape[1])).argmax(1)
+        correct += int((pred == labels[a:a + 128]).sum())
+        total += x.shape[0]
+    return correct / max(total, 1)
+
+
+def main(argv=None):
+    args = parse_args(argv)
+    if not torch.cuda.is_available():
+        raise SystemExit("wfd_gan_amd needs an MI355X (HIP device); there is no CPU path")
+    device = torch.device(f"cuda:{args.cuda_id}")
+    torch.cuda.set_device(device)
+    if args.seed is not None:
+        torch.manual_seed(args.seed)
+        np.random.seed(args.seed)
+
+    pardir, modeldir, checkpointdir = utils.init_directory(args.dir, tag="training_{}".format(strftime("%m%d_%H%M%S")))
+    logger = utils.init_logger("gan", join(pardir, "log.txt"))
+    logger.info(args)
+    logger.debug("Output to {}".format(pardir))
+    with open(join(pardir, "args.json"), "wt") as f:
+        json.dump(vars(args), f, indent=4)
+
+    X, y = utils.load_dataset(args.dir)
+    logger.info("Loaded dataset:{}, min burst:{} max burst:{}, min label:{}, max label:{}"
+                .format(X.shape, X[:, 1:].min(), X[:, 1:].max(), y.min(), y.max()))
+    if args.clip:
+        X = clip_dataset(X, device)
+        np.savez_compressed(args.dir.split(".npz")[0] + "_clip.npz", features=X, labels=y)
+        logger.info("Save back  the clipped dataset to {}".format(args.dir.split(".npz")[0] + "_clip.npz"))
+    y = y - y.min()
+
+    scaler = preprocessing.MinMaxScaler()
+    Xs = scaler.fit_transform(X)                      # float64 on the host, once
+    class_dim = len(np.unique(y))
+    N, seq_len = Xs.shape
+    assert seq_len > 1 and class_dim > 1
+    logger.info("X shape {}, y shape {}, class num: {}".format(Xs.shape, y.shape, class_dim))
+
+    # modules in the reference's construction order (:150-153) so that a seed gives the same initial weights
+    generator = Generator(seq_len, class_dim, args.latent_dim, scaler_min=scaler.data_min_[0],
+                          scaler_max=scaler.data_max_[0], is_gpu=True)
+    discriminator = Discriminator(seq_len, class_dim)
+    f_model = DF(seq_len - 1, class_dim)
+    f_model.load_state_dict(torch.load(args.f_model, map_location="cpu", weights_only=True))
+    f_model.eval().to(device)
+
+    B = min(args.batch_size, N)
+    seed = args.seed if args.seed is not None else int(torch.initial_seed() & 0x7FFFFFFF)
+    eng = TrainEngine(seq_len, class_dim, args.latent_dim, B, scaler.data_min_[0], scaler.data_max_[0],
+                      generator.state_dict(), discriminator.state_dict(), f_model.state_dict(), lr=args.lr,
+                      alpha=args.alpha, n_critic=args.n_critic, penalty=args.penalty, lambda_gp=cm.lambda_gp,
+                      device=device, seed=seed)
+    eng.attach_dataset(torch.from_numpy(Xs), torch.from_numpy(y), shuffle_seed=seed)
+    if not args.no_graph:
+        eng.capture_graphs()
+    n_full, tail_rows = N // B, N % B
+    tail = None
+    if tail_rows > 1:       # the DataLoader's ragged last batch (drop_last=False); BatchNorm needs > 1 row
+        tail = TrainEngine(seq_len, class_dim, args.latent_dim, tail_rows, scaler.data_min_[0], scaler.data_max_[0],
+                           {}, {}, {}, lr=args.lr, alpha=args.alpha, n_critic=args.n_critic, penalty=args.penalty,
+                           lambda_gp=cm.lambda_gp, device=device, seed=seed + 1, share=eng)
+    n_batches = n_full + (1 if tail is not None else 0)
+    n_gsteps = (n_batches + args.n_critic - 1) // args.n_critic
+    cap = n_gsteps * B
+    ep_fake = torch.zeros(cap, seq_len, dtype=torch.float32, device=device)
+    ep_idx = torch.zeros(cap, dtype=torch.int64, device=device)
+    y_dev = torch.from_numpy(y).to(device)
+
+    losses = {"generator": [], "discriminator": [], "dist": []}
+    for epoch in range(args.n_epochs):
+        eng.buf["dacc"].zero_()
+        eng.buf["gacc"].zero_()
+        fill = 0
+        for i in range(n_batches):
+            do_g = (i % args.n_critic == 0)
+            if i < n_full:
+                eng.iteration(i)
+                src, rows, idx = eng, B, eng.perm[i * B:(i + 1) * B]
+            else:
+                idx = eng.perm[n_full * B:]
+                tail.set_batch(eng.data_X[idx], y_dev[idx], torch.zeros(tail_rows, args.latent_dim))
+                tail.draw_z()
+                tail.draw_masks(do_g)
+                tail.d_step()
+                if do_g:
+                    tail.g_step()
+                src, rows = tail, tail_rows
+            if do_g:        # total_real / total_fake / total_c of :241-243, kept on device
+                ep_fake[fill:fill + rows].copy_(src.fake_rows[:, :seq_len])
+                ep_idx[fill:fill + rows].copy_(idx)
+                fill += rows
+        eng.reshuffle()
+        eng.check_length_index()
+        dacc, gacc = eng.buf["dacc"].tolist(), eng.buf["gacc"].tolist()      # the epoch's only host sync
+        d_ep, w_ep = dacc[0] / n_batches, dacc[1] / n_batches
+        div_g = max(n_batches // args.n_critic, 1)
+        g_ep, f_ep, comb_ep = gacc[0] / div_g, gacc[1] / div_g, gacc[2] / div_g
+        df_acc = df_accuracy(f_model, ep_fake[:fill], y_dev[ep_idx[:fill]])
+        logger.info(
+            "[Epoch %2d/%2d] [D loss: %.4f] [G loss: %.4f + %.4f * %.4f = %.4f] [DF acc: %.4f] [w dist: %.4f]"
+            % (epoch + 1, args.n_epochs, d_ep, g_ep, args.alpha, f_ep, comb_ep, df_acc, w_ep))
+        stop = w_ep <= w_dist_threshold and df_acc >= 0.9
+        if epoch == 0 or (epoch + 1) % args.freq == 0 or stop:
+            sel = ep_idx[:fill].cpu().numpy()
+            total_real = scaler.inverse_transform(Xs[sel])                               # float64
+            total_fake = scaler.inverse_transform(ep_fake[:fill].cpu().numpy())          # float32
+            np.savez_compressed(join(checkpointdir, "epoch_{}".format(epoch + 1)), x=total_real, recon_x=total_fake,
+                                label=y[sel])
+        losses["generator"].append(g_ep)
+        losses["discriminator"].append(d_ep)
+        losses["dist"].append(w_ep)
+        if stop:
+            logger.info("Early stopping since the w-dist = {}, df acc = {}.".format(w_ep, df_acc))
+            break
+
+    np.savez_compressed(join(checkpointdir, "loss.npz"), generator=losses["generator"],
+                        discriminator=losses["discriminator"], dist=losses["dist"])
+    torch.save({k: v.cpu() for k, v in eng.generator_state().items()},
+               join(modeldir, "generator_seqlen{}_cls{}_latentdim{}.ckpt".format(seq_len, class_dim, args.latent_dim)))
+    torch.save({k: v.cpu() for k, v in eng.discriminator_state().items()}, join(modeldir, "discriminator.ckpt"))
+    logger.info("Model saved at {}".format(modeldir))
+    joblib.dump(scaler, join(modeldir, "scaler.gz"))
+    logger.info("Scaler saved at {}".format(modeldir))
+    return pardir
+
+
+if __name__ == "__main__":
+    main()
