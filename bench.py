@@ -68,9 +68,7 @@ def build_engine(args, rank, world, device):
 
 def run_steps(eng, start, n):
     for i in range(start, start + n):
-        eng.iteration(i)
-        if (i + 1) % eng.iters_per_epoch == 0:
-            eng.reshuffle()
+        eng.iteration(i)          # re-permutes by itself at epoch ends
 
 
 def gemm_roofline(eng, n_iters=6):

@@ -546,6 +546,8 @@ class TrainEngine:
         self.data_y = y.to(self.dev, torch.int32).contiguous()
         self.N = self.data_X.shape[0]
         self.iters_per_epoch = self.N // self.B          # full batches; the trainer handles a ragged tail
+        self.auto_reshuffle = True                       # iteration() starts a new permutation when one is used up
+        self._pos = 0
         self.iter_state = torch.zeros(2, dtype=torch.int64, device=self.dev)   # [philox counter, perm cursor]
         self.perm_gen = torch.Generator(device=self.dev)
         self.perm_gen.manual_seed(shuffle_seed)
@@ -556,13 +558,14 @@ class TrainEngine:
         """New epoch permutation (DataLoader(shuffle=True), src/mlp_df_wgan_train.py:142-147); cursor back to 0."""
         self.perm.copy_(torch.randperm(self.N, generator=self.perm_gen, device=self.dev))
         self.iter_state[1] = 0
+        self._pos = 0
 
     def _build_fast_plans(self):
         B, S, C, Z, b = self.B, self.S, self.C, self.Z, self.buf
         st = self.iter_state.data_ptr()
         gold = 0x9E3779B97F4A7C15
         pd = Plan(b["ws"])
-        pd.add(self.L.gather_batch, ptr(self.data_X), S, ptr(self.data_y), ptr(self.perm), st, B, S, C,
+        pd.add(self.L.gather_batch, ptr(self.data_X), S, ptr(self.data_y), ptr(self.perm), st, self.N, self.N, B, S, C,
                ptr(self.real_rows), ptr(self.fake_rows), self.ldx, ptr(b["ZIN"]), self.ldz, Z, ptr(b["labels"]))
         pd.add(self.L.rng_normal_rows, ptr(b["ZIN"]), self.ldz, B, Z, (self.seed + 7 * gold) & (2**64 - 1), st, 0)
         inc = (B * Z + 3) // 4
@@ -643,4 +646,7 @@ class TrainEngine:
         k = 2 if do_g else 1
         self.nbt["model.3"] += k
         self.nbt["model.6"] += k
+        self._pos += 1
+        if self.auto_reshuffle and self._pos >= self.iters_per_epoch:
+            self.reshuffle()
         return do_g

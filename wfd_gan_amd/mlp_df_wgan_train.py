@@ -128,6 +128,7 @@ def main(argv=None):
                       alpha=args.alpha, n_critic=args.n_critic, penalty=args.penalty, lambda_gp=cm.lambda_gp,
                       device=device, seed=seed)
     eng.attach_dataset(torch.from_numpy(Xs), torch.from_numpy(y), shuffle_seed=seed)
+    eng.auto_reshuffle = False        # the epoch loop below owns the permutation (ragged last batch)
     if not args.no_graph:
         eng.capture_graphs()
     n_full, tail_rows = N // B, N % B
