@@ -77,6 +77,11 @@ int wfd_ep_penalty_row(const float* P, int ns, long ss, int ldp, int M, int S, i
 int wfd_colsum(const float* X, int ldx, int M, int N, const float* rowscale, float* out, int accumulate,
                void* stream);
 
+/* All column sums of a step in one launch.  desc (DEVICE memory) holds 10 64-bit words per segment:
+ * [X, ldx, rowscale, X2, ldx2, rowscale2, M, N, out, first_block]; out[n] = sum_m X[m][n]*rs[m] (+ the same over
+ * X2); pointers may be 0 (rowscale = 1, no second source).  Blocks cover 32 columns each. */
+int wfd_colsum_multi(const long long* desc, int nseg, int total_blocks, void* stream);
+
 /* torch.optim.RMSprop.step with torch defaults (alpha .99, eps 1e-8), src/mlp_df_wgan_train.py:163-164,230,275,
  * over one flat parameter buffer; g is multiplied by gscale first (1/world_size after an all-reduce). */
 int wfd_rmsprop(float* p, const float* g, float* sq, long n, float lr, float alpha, float eps, float gscale,

@@ -15,10 +15,19 @@
 
 namespace {
 
+// Sum of the split-K slabs of one element, in a fixed order (4 independent partial sums keep 4 loads in flight).
 __device__ __forceinline__ float slab_sum(const float* __restrict__ P, int ns, long ss, long idx) {
-    float a = P[idx];
-    for (int z = 1; z < ns; ++z) a += P[(long)z * ss + idx];
-    return a;
+    const float* p = P + idx;
+    float a0 = p[0], a1 = 0.f, a2 = 0.f, a3 = 0.f;
+    int z = 1;
+    for (; z + 3 < ns; z += 4) {
+        a1 += p[(long)z * ss];
+        a2 += p[(long)(z + 1) * ss];
+        a3 += p[(long)(z + 2) * ss];
+        a0 += p[(long)(z + 3) * ss];
+    }
+    for (; z < ns; ++z) a1 += p[(long)z * ss];
+    return (a0 + a1) + (a2 + a3);
 }
 
 __device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + __expf(-x)); }
@@ -31,10 +40,19 @@ __device__ __forceinline__ float4 slab_sum4(const float* __restrict__ P, int ns,
     float4 a;
     if constexpr (VEC) {
         a = *reinterpret_cast<const float4*>(P + idx);
-        for (int z = 1; z < ns; ++z) {
-            const float4 b = *reinterpret_cast<const float4*>(P + (long)z * ss + idx);
-            a.x += b.x; a.y += b.y; a.z += b.z; a.w += b.w;
+        float4 c = make_float4(0.f, 0.f, 0.f, 0.f);
+        int z = 1;
+        for (; z + 1 < ns; z += 2) {
+            const float4 b0 = *reinterpret_cast<const float4*>(P + (long)z * ss + idx);
+            const float4 b1 = *reinterpret_cast<const float4*>(P + (long)(z + 1) * ss + idx);
+            a.x += b0.x; a.y += b0.y; a.z += b0.z; a.w += b0.w;
+            c.x += b1.x; c.y += b1.y; c.z += b1.z; c.w += b1.w;
         }
+        if (z < ns) {
+            const float4 b0 = *reinterpret_cast<const float4*>(P + (long)z * ss + idx);
+            a.x += b0.x; a.y += b0.y; a.z += b0.z; a.w += b0.w;
+        }
+        a.x += c.x; a.y += c.y; a.z += c.z; a.w += c.w;
     } else {
         float t[4] = {0.f, 0.f, 0.f, 0.f};
         for (int k = 0; k < nvalid; ++k) t[k] = slab_sum(P, ns, ss, idx + k);
@@ -197,9 +215,9 @@ __global__ void ep_penalty_row_kernel(const float* __restrict__ P, int ns, long 
     for (int j = threadIdx.x; j < S; j += blockDim.x) GH[(long)m * ldg + j] = coef * grow[j];
 }
 
-// Column-reduction kernels use 32 columns x 8 row groups per workgroup (coalesced 128-B row segments, LDS
+// Column-reduction kernels use 32 columns x 16 row groups per workgroup (coalesced 128-B row segments, LDS
 // reduce over the row groups) so that a 64..128-row batch still spreads over N/32 workgroups.
-constexpr int CT = 32, RG = 8;
+constexpr int CT = 32, RG = 16;
 
 __device__ __forceinline__ float rg_reduce(float v, float (*red)[CT]) {
     __syncthreads();
@@ -221,6 +239,34 @@ __global__ void colsum_kernel(const float* __restrict__ X, int ldx, int M, int N
         for (int m = threadIdx.y; m < M; m += RG) a += X[(long)m * ldx + n] * (rowscale ? rowscale[m] : 1.f);
     a = rg_reduce(a, red);
     if (n < N && threadIdx.y == 0) out[n] = accumulate ? out[n] + a : a;
+}
+
+// Several column sums in ONE launch (all bias / head gradients of a step).  desc holds, per segment, 10 words:
+//   [X, ldx, rowscale, X2, ldx2, rowscale2, M, N, out, first_block]   (X2 = 0: single source)
+//   out[n] = sum_m X[m][n] * rs[m] + sum_m X2[m][n] * rs2[m]
+__global__ void colsum_multi_kernel(const long long* __restrict__ desc, int nseg) {
+    __shared__ float red[RG][CT];
+    int sgi = 0;
+    for (int k = 1; k < nseg; ++k)
+        if ((int)desc[k * 10 + 9] <= (int)blockIdx.x) sgi = k;
+    const long long* d = desc + sgi * 10;
+    const float* X = reinterpret_cast<const float*>(d[0]);
+    const int ldx = (int)d[1];
+    const float* rs = reinterpret_cast<const float*>(d[2]);
+    const float* X2 = reinterpret_cast<const float*>(d[3]);
+    const int ldx2 = (int)d[4];
+    const float* rs2 = reinterpret_cast<const float*>(d[5]);
+    const int M = (int)d[6], N = (int)d[7];
+    float* out = reinterpret_cast<float*>(d[8]);
+    const int n = ((int)blockIdx.x - (int)d[9]) * CT + threadIdx.x;
+    float a = 0.f;
+    if (n < N)
+        for (int m = threadIdx.y; m < M; m += RG) {
+            a += X[(long)m * ldx + n] * (rs ? rs[m] : 1.f);
+            if (X2) a += X2[(long)m * ldx2 + n] * (rs2 ? rs2[m] : 1.f);
+        }
+    a = rg_reduce(a, red);
+    if (n < N && threadIdx.y == 0) out[n] = a;
 }
 
 // RMSprop (torch defaults: alpha .99, eps 1e-8, no momentum, not centered, wd 0), one flat pass
@@ -526,7 +572,7 @@ int wfd_ep_mul(const float* P, int ns, long ss, int ldp, int M, int N, const flo
 int wfd_ep_penalty_row(const float* P, int ns, long ss, int ldp, int M, int S, int mode, float invB, float lambda,
                        const float* rowflag, float* nsq, float* pen, float* GH, int ldg, void* stream) {
     if (!P || !nsq || !pen || !GH || S <= 0 || (size_t)S * 4 > 60000) return WFD_ERR_ARG;
-    hipLaunchKernelGGL(ep_penalty_row_kernel, dim3(M), dim3(256), (size_t)S * sizeof(float), (hipStream_t)stream, P, ns,
+    hipLaunchKernelGGL(ep_penalty_row_kernel, dim3(M), dim3(512), (size_t)S * sizeof(float), (hipStream_t)stream, P, ns,
                        ss, ldp, S, mode, invB, lambda, rowflag, nsq, pen, GH, ldg);
     WFD_CHECK_LAUNCH();
     return WFD_OK;
@@ -537,6 +583,13 @@ int wfd_colsum(const float* X, int ldx, int M, int N, const float* rowscale, flo
     if (!X || !out) return WFD_ERR_ARG;
     hipLaunchKernelGGL(colsum_kernel, dim3(cdiv(N, CT)), dim3(CT, RG), 0, (hipStream_t)stream, X, ldx, M, N, rowscale,
                        out, accumulate);
+    WFD_CHECK_LAUNCH();
+    return WFD_OK;
+}
+
+int wfd_colsum_multi(const long long* desc, int nseg, int total_blocks, void* stream) {
+    if (!desc || nseg <= 0 || total_blocks <= 0) return WFD_ERR_ARG;
+    hipLaunchKernelGGL(colsum_multi_kernel, dim3(total_blocks), dim3(CT, RG), 0, (hipStream_t)stream, desc, nseg);
     WFD_CHECK_LAUNCH();
     return WFD_OK;
 }
@@ -596,7 +649,7 @@ int wfd_bn_bwd(const float* P, int ns, long ss, int ldp, int M, int N, const flo
 int wfd_ep_sigmoid_lenmask(const float* P, int ns, long ss, int ldp, int M, int S, const float* bias, float range,
                            float smin, float* out, int ldo, int* idx, int* err, void* stream) {
     if (!P || !bias || !out || !idx || !err) return WFD_ERR_ARG;
-    hipLaunchKernelGGL(ep_sigmoid_lenmask_kernel, dim3(M), dim3(256), 0, (hipStream_t)stream, P, ns, ss, ldp, S, bias,
+    hipLaunchKernelGGL(ep_sigmoid_lenmask_kernel, dim3(M), dim3(512), 0, (hipStream_t)stream, P, ns, ss, ldp, S, bias,
                        range, smin, out, ldo, idx, err);
     WFD_CHECK_LAUNCH();
     return WFD_OK;

@@ -207,8 +207,9 @@ class TrainEngine:
         b["XC"] = z(2 * M, ldx)          # rows [0,M): penalty seeds ghat ; rows [M,2M): D inputs [x|c]
         b["ZIN"] = z(B, ldz)             # generator input [z|c]
         b["labels"] = torch.zeros(B, dtype=torch.int32, device=dev)
-        for i, n in ((1, 2048), (2, 1024), (3, 512)):
-            b[f"MK{i}"] = z(M, n)        # dropout keep-masks {0,1.25}
+        b["MKflat"] = z(M * 3584)        # the three dropout keep-masks {0,1.25}, one RNG launch
+        for i, n, o in ((1, 2048, 0), (2, 1024, 2048), (3, 512, 3072)):
+            b[f"MK{i}"] = b["MKflat"][M * o: M * (o + n)].view(M, n)
             b[f"D{i}"] = z(M, n)         # local derivatives d_i
             b[f"DL{i}"] = z(2 * M, n)    # [delta_i ; dv o delta_i]
         b["T1H1"] = z(2 * M, 2048)       # [t_1 ; h_1]
@@ -231,8 +232,10 @@ class TrainEngine:
         b["idx"] = torch.zeros(B, dtype=torch.int32, device=dev)
         b["err"] = torch.zeros(1, dtype=torch.int32, device=dev)
         # G-step critic pass (fake rows only)
-        for i, n in ((1, 2048), (2, 1024), (3, 512)):
-            b[f"gMK{i}"], b[f"gD{i}"], b[f"gDL{i}"] = z(B, n), z(B, n), z(B, n)
+        b["gMKflat"] = z(B * 3584)
+        for i, n, o in ((1, 2048, 0), (2, 1024, 2048), (3, 512, 3072)):
+            b[f"gMK{i}"] = b["gMKflat"][B * o: B * (o + n)].view(B, n)
+            b[f"gD{i}"], b[f"gDL{i}"] = z(B, n), z(B, n)
         b["gH1"], b["gH2"], b["gH3"], b["gV"] = z(B, 2048), z(B, 1024), z(B, 512), z(B)
         # observer
         df = self.df
@@ -357,15 +360,25 @@ class TrainEngine:
         p.gemm(TN, b["DL1"], 2048, b["XC"], self.ldx, 2048, S + C, 2 * M, out=D.g["model.0.weight"], ldp=S + C)
         p.gemm(TN, b["DL2"], 1024, b["T1H1"], 2048, 1024, 2048, 2 * M, out=D.g["model.3.weight"], ldp=2048)
         p.gemm(TN, b["DL3"], 512, b["T2H2"], 1024, 512, 1024, 2 * M, out=D.g["model.6.weight"], ldp=1024)
-        p.add(self.L.colsum, ptr(b["DL1"][M:]), 2048, M, 2048, 0, ptr(D.g["model.0.bias"]), 0)
-        p.add(self.L.colsum, ptr(b["DL2"][M:]), 1024, M, 1024, 0, ptr(D.g["model.3.bias"]), 0)
-        p.add(self.L.colsum, ptr(b["DL3"][M:]), 512, M, 512, 0, ptr(D.g["model.6.bias"]), 0)
-        p.add(self.L.colsum, ptr(b["T3"]), 512, M, 512, 0, ptr(D.g["model.9.weight"]), 0)
-        p.add(self.L.colsum, ptr(b["H3"]), 512, M, 512, ptr(b["DV"]), ptr(D.g["model.9.weight"]), 1)
-        p.add(self.L.colsum, ptr(b["DV"]), 1, M, 1, 0, ptr(D.g["model.9.bias"]), 0)
+        self._colsum_multi(p, "d_small", [
+            (b["DL1"][M:], 2048, None, None, 0, None, M, 2048, D.g["model.0.bias"]),
+            (b["DL2"][M:], 1024, None, None, 0, None, M, 1024, D.g["model.3.bias"]),
+            (b["DL3"][M:], 512, None, None, 0, None, M, 512, D.g["model.6.bias"]),
+            (b["T3"], 512, None, b["H3"], 512, b["DV"], M, 512, D.g["model.9.weight"]),
+            (b["DV"], 1, None, None, 0, None, M, 1, D.g["model.9.bias"])])
         self._grad_sync_hook(p, "D")
         p.add(self.L.rmsprop, ptr(D.flat), ptr(D.grad), ptr(D.sq), D.numel, self.lr, 0.99, 1e-8, 1.0 / self.world)
         return p
+
+    def _colsum_multi(self, p: Plan, name: str, segs):
+        """segs: (X, ldx, rowscale, X2, ldx2, rowscale2, M, N, out) -> one launch of wfd_colsum_multi."""
+        rows, blk = [], 0
+        for X, ldx, rs, X2, ldx2, rs2, M, N, out in segs:
+            rows.append([ptr(X), ldx, ptr(rs), ptr(X2), ldx2, ptr(rs2), M, N, ptr(out), blk])
+            blk += (N + 31) // 32
+        desc = torch.tensor(rows, dtype=torch.int64, device=self.dev)
+        self.buf["desc_" + name] = desc
+        p.add(self.L.colsum_multi, ptr(desc), len(rows), blk)
 
     def _grad_sync_hook(self, p: Plan, which: str):
         if self.world > 1:
@@ -487,12 +500,12 @@ class TrainEngine:
     def draw_masks(self, g_step: bool):
         """Fast mode: Philox keep-masks on device (one launch per mask tensor)."""
         st = torch.cuda.current_stream().cuda_stream
-        names = ["MK1", "MK2", "MK3"] + (["gMK1", "gMK2", "gMK3"] if g_step else [])
+        names = ["MKflat"] + (["gMKflat"] if g_step else [])
         for k, nme in enumerate(names):
             t = self.buf[nme]
             self.L.rng_dropout_mask(t.data_ptr(), t.numel(), 0.2, (self.seed + 31 * (k + 1)) & (2**64 - 1), 0,
                                     self.rng_offset, st)
-        self.rng_offset += (self.buf["MK1"].numel() + 3) // 4
+        self.rng_offset += (self.buf["MKflat"].numel() + 3) // 4
 
     def draw_z(self):
         st = torch.cuda.current_stream().cuda_stream
@@ -568,19 +581,16 @@ class TrainEngine:
         pd.add(self.L.gather_batch, ptr(self.data_X), S, ptr(self.data_y), ptr(self.perm), st, self.N, self.N, B, S, C,
                ptr(self.real_rows), ptr(self.fake_rows), self.ldx, ptr(b["ZIN"]), self.ldz, Z, ptr(b["labels"]))
         pd.add(self.L.rng_normal_rows, ptr(b["ZIN"]), self.ldz, B, Z, (self.seed + 7 * gold) & (2**64 - 1), st, 0)
-        inc = (B * Z + 3) // 4
-        for k, nme in enumerate(("MK1", "MK2", "MK3")):
-            t = b[nme]
-            pd.add(self.L.rng_dropout_mask, ptr(t), t.numel(), 0.2, (self.seed + (k + 1) * gold) & (2**64 - 1), st, 0)
-            inc = max(inc, (t.numel() + 3) // 4)
+        t = b["MKflat"]
+        pd.add(self.L.rng_dropout_mask, ptr(t), t.numel(), 0.2, (self.seed + gold) & (2**64 - 1), st, 0)
+        inc = max((B * Z + 3) // 4, (t.numel() + 3) // 4)
         if self.penalty == "gp":
             pd.add(self.L.rng_uniform, ptr(b["GPA"]), B, (self.seed + 11 * gold) & (2**64 - 1), st, 0)
         pd.calls += self.plan_d.calls
         pd.add(self.L.iter_advance, st, inc, B)
         pg = Plan(b["ws"])
-        for k, nme in enumerate(("gMK1", "gMK2", "gMK3")):
-            t = b[nme]
-            pg.add(self.L.rng_dropout_mask, ptr(t), t.numel(), 0.2, (self.seed + (k + 4) * gold) & (2**64 - 1), st, 0)
+        t = b["gMKflat"]
+        pg.add(self.L.rng_dropout_mask, ptr(t), t.numel(), 0.2, (self.seed + 4 * gold) & (2**64 - 1), st, 0)
         pg.calls += self.plan_g.calls
         pg.add(self.L.iter_advance, st, inc, 0)
         return pd, pg
