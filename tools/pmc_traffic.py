@@ -1,0 +1,38 @@
+#!/usr/bin/env python3
+"""Summarise rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes (separate runs) per kernel.
+
+    python tools/pmc_traffic.py gpurun_out/pmc_fetch gpurun_out/pmc_write profiles/r01_pmc_traffic.json
+
+Units and gfx950 correction per MI355X_MICROARCH.md §HBM: the counters are in KiB; FETCH_SIZE reports half of the
+bytes of wide coalesced streaming reads, so read bytes = 2 * FETCH_SIZE * 1024; WRITE_SIZE is exact.
+"""
+import csv, glob, json, re, sys
+from collections import defaultdict
+
+def short(name):
+    m = re.search(r"(gemm_f32_kernel<[^>]*>|[A-Za-z0-9_]+_kernel)", name)
+    return m.group(1) if m else name[:60]
+
+def load(d, counter):
+    out = defaultdict(list)
+    for f in glob.glob(d + "/*/*counter_collection.csv"):
+        for r in csv.DictReader(open(f)):
+            if r["Counter_Name"] == counter:
+                out[short(r["Kernel_Name"])].append(float(r["Counter_Value"]))
+    return out
+
+fetch, write = load(sys.argv[1], "FETCH_SIZE"), load(sys.argv[2], "WRITE_SIZE")
+res = {}
+for k in sorted(set(fetch) | set(write)):
+    f, w = fetch.get(k, []), write.get(k, [])
+    if not (k.startswith("gemm") or k.endswith("_kernel")) or "at::" in k:
+        continue
+    rd = 2.0 * 1024 * sum(f) / max(len(f), 1)
+    wr = 1024.0 * sum(w) / max(len(w), 1)
+    res[k] = dict(launches=len(f), read_bytes_per_launch=rd, write_bytes_per_launch=wr, hbm_bytes_per_launch=rd + wr)
+g = [v for k, v in res.items() if k.startswith("gemm")]
+n = sum(v["launches"] for v in g)
+res["_gemm_all"] = dict(launches=n, hbm_bytes_per_launch=sum(v["hbm_bytes_per_launch"] * v["launches"] for v in g) / max(n, 1))
+json.dump(res, open(sys.argv[3], "w"), indent=1)
+for k, v in res.items():
+    print(f"{k:60s} n={v['launches']:5d} hbm/launch={v['hbm_bytes_per_launch']/1e6:8.3f} MB")
