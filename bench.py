@@ -61,7 +61,7 @@ def build_engine(args, rank, world, device):
     pg = None
     eng = TrainEngine(S, C, Z, B, float(dmin[0]), float(dmax[0]), G.state_dict(), D.state_dict(), F.state_dict(),
                       lr=2e-4, alpha=0.02, n_critic=3, penalty=args.penalty, device=device, seed=1234 + rank,
-                      process_group=pg, world_size=world)
+                      process_group=pg, world_size=world, overlap=bool(args.overlap))
     eng.attach_dataset(Xs, y, shuffle_seed=rank)
     return eng, (dmin.double().cpu().numpy(), dmax.double().cpu().numpy())
 
@@ -77,12 +77,15 @@ def gemm_roofline(eng, n_iters=6):
     from wfd_gan_amd.plan import HOST
     L = eng.L
     gemm_fns = {L.gemm_f32: "gemm", L.conv8_gemm_f32: "conv"}
+    from wfd_gan_amd.plan import FORK, JOIN
     stream = torch.cuda.current_stream().cuda_stream
     recs = []
     for it in range(n_iters):
         plans = [eng.fast_d] + ([eng.fast_g] if it % eng.n_critic == 0 else [])
         for plan in plans:
-            for fn, a in plan.calls:
+            for fn, a, _lane in plan.calls:       # everything on ONE stream here: each launch is timed alone
+                if fn is FORK or fn is JOIN:
+                    continue
                 if fn is HOST:
                     a[0]()
                     continue
@@ -149,6 +152,7 @@ def main():
     ap.add_argument("--latent_dim", type=int, default=500)
     ap.add_argument("--penalty", default="div", choices=["div", "gp"])
     ap.add_argument("--no-graph", action="store_true")
+    ap.add_argument("--overlap", type=int, default=0, help="1: independent branches of a step on a side stream")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-sampling", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=20.0)

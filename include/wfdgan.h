@@ -77,21 +77,28 @@ int wfd_ep_penalty_row(const float* P, int ns, long ss, int ldp, int M, int S, i
 int wfd_colsum(const float* X, int ldx, int M, int N, const float* rowscale, float* out, int accumulate,
                void* stream);
 
-/* All column sums of a step in one launch.  desc (DEVICE memory) holds 10 64-bit words per segment:
- * [X, ldx, rowscale, X2, ldx2, rowscale2, M, N, out, first_block]; out[n] = sum_m X[m][n]*rs[m] (+ the same over
- * X2); pointers may be 0 (rowscale = 1, no second source).  Blocks cover 32 columns each. */
+/* All column sums of a step in one launch.  desc (DEVICE memory) holds 11 64-bit words per segment:
+ * [X, ldx, rowscale, X2, ldx2, rowscale2, M, N, out, first_block, acc]; out[n] = sum_m X[m][n]*rs[m] (+ the same
+ * over X2), acc[n] += out[n]; pointers may be 0 (rowscale = 1, no second source, no accumulator).  Blocks cover 32
+ * columns each.  With N = 1 segments this also produces the step's loss scalars (:218,226-227) on device. */
 int wfd_colsum_multi(const long long* desc, int nseg, int total_blocks, void* stream);
 
 /* torch.optim.RMSprop.step with torch defaults (alpha .99, eps 1e-8), src/mlp_df_wgan_train.py:163-164,230,275,
- * over one flat parameter buffer; g is multiplied by gscale first (1/world_size after an all-reduce). */
+ * over one flat parameter buffer; g is multiplied by gscale first (1/world_size after an all-reduce).  As the
+ * last kernel of a step it can also do the step's bookkeeping: state[0] += inc0, state[1] += inc1 (state may be
+ * NULL), see wfd_iter_advance. */
 int wfd_rmsprop(float* p, const float* g, float* sq, long n, float lr, float alpha, float eps, float gscale,
-                void* stream);
+                unsigned long long* state, unsigned long long inc0, unsigned long long inc1, void* stream);
 
 /* nn.BatchNorm1d(n, eps=0.8) training forward (src/model.py:23), in two halves so that data-parallel ranks can
  * combine (mean, M2) in between: stats writes Z = sumP + bias and the per-column mean / sum of squared deviations;
- * apply writes xhat, relu(gamma*xhat+beta), invstd and updates running_mean / running_var (unbiased) nupd times. */
+ * apply writes xhat, relu(gamma*xhat+beta), invstd and updates running_mean / running_var (unbiased) nupd times.
+ * wfd_bn_train_relu is both halves in one launch (single rank). */
 int wfd_bn_stats(const float* P, int ns, long ss, int ldp, int M, int N, const float* bias, float* Z, int ldz,
                  float* mean, float* m2, void* stream);
+int wfd_bn_train_relu(const float* P, int ns, long ss, int ldp, int M, int N, const float* bias, float eps,
+                      const float* gamma, const float* beta, float* XH, float* H, int ldo, float* mean, float* m2,
+                      float* invstd, float* rmean, float* rvar, float momentum, int nupd, void* stream);
 int wfd_bn_apply_relu(const float* Z, int ldz, int M, int N, const float* mean, const float* m2, float count, float eps,
                       const float* gamma, const float* beta, float* XH, float* H, int ldo, float* invstd, float* rmean,
                       float* rvar, float momentum, int nupd, void* stream);
@@ -157,6 +164,10 @@ int wfd_rng_dropout_mask(float* out, long n, float p, unsigned long long seed, c
 /* z ~ N(0,1) (np.random.normal, src/mlp_df_wgan_train.py:194; np.random.randn, src/generate.py:53) on device */
 int wfd_rng_normal_rows(float* out, int ld, int M, int Z, unsigned long long seed, const unsigned long long* state,
                         unsigned long long base, void* stream);
+
+/* z and the step's dropout keep-masks in one launch (wfd_rng_normal_rows + wfd_rng_dropout_mask, same streams) */
+int wfd_rng_step_inputs(float* zout, int ld, int M, int Z, unsigned long long zseed, float* mout, long nmask, float p,
+                        unsigned long long mseed, const unsigned long long* state, void* stream);
 
 /* U[0,1) interpolation weights (np.random.random((B,1)), src/utils.py:67) */
 int wfd_rng_uniform(float* out, long n, unsigned long long seed, const unsigned long long* state,

@@ -241,15 +241,15 @@ __global__ void colsum_kernel(const float* __restrict__ X, int ldx, int M, int N
     if (n < N && threadIdx.y == 0) out[n] = accumulate ? out[n] + a : a;
 }
 
-// Several column sums in ONE launch (all bias / head gradients of a step).  desc holds, per segment, 10 words:
-//   [X, ldx, rowscale, X2, ldx2, rowscale2, M, N, out, first_block]   (X2 = 0: single source)
-//   out[n] = sum_m X[m][n] * rs[m] + sum_m X2[m][n] * rs2[m]
+// Several column sums in ONE launch (all bias / head gradients and the loss scalars of a step).  desc holds, per
+// segment, 11 words: [X, ldx, rowscale, X2, ldx2, rowscale2, M, N, out, first_block, acc]   (X2 = 0: single source)
+//   out[n] = sum_m X[m][n] * rs[m] + sum_m X2[m][n] * rs2[m];   acc[n] += out[n] when acc != 0 (epoch sums)
 __global__ void colsum_multi_kernel(const long long* __restrict__ desc, int nseg) {
     __shared__ float red[RG][CT];
     int sgi = 0;
     for (int k = 1; k < nseg; ++k)
-        if ((int)desc[k * 10 + 9] <= (int)blockIdx.x) sgi = k;
-    const long long* d = desc + sgi * 10;
+        if ((int)desc[k * 11 + 9] <= (int)blockIdx.x) sgi = k;
+    const long long* d = desc + sgi * 11;
     const float* X = reinterpret_cast<const float*>(d[0]);
     const int ldx = (int)d[1];
     const float* rs = reinterpret_cast<const float*>(d[2]);
@@ -258,6 +258,7 @@ __global__ void colsum_multi_kernel(const long long* __restrict__ desc, int nseg
     const float* rs2 = reinterpret_cast<const float*>(d[5]);
     const int M = (int)d[6], N = (int)d[7];
     float* out = reinterpret_cast<float*>(d[8]);
+    float* acc = reinterpret_cast<float*>(d[10]);
     const int n = ((int)blockIdx.x - (int)d[9]) * CT + threadIdx.x;
     float a = 0.f;
     if (n < N)
@@ -266,12 +267,20 @@ __global__ void colsum_multi_kernel(const long long* __restrict__ desc, int nseg
             if (X2) a += X2[(long)m * ldx2 + n] * (rs2 ? rs2[m] : 1.f);
         }
     a = rg_reduce(a, red);
-    if (n < N && threadIdx.y == 0) out[n] = a;
+    if (n < N && threadIdx.y == 0) {
+        out[n] = a;
+        if (acc) acc[n] += a;
+    }
 }
 
 // RMSprop (torch defaults: alpha .99, eps 1e-8, no momentum, not centered, wd 0), one flat pass
 __global__ void rmsprop_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ sq, long n,
-                               float lr, float alpha, float eps, float gscale) {
+                               float lr, float alpha, float eps, float gscale,
+                               unsigned long long* __restrict__ state, unsigned long long inc0,
+                               unsigned long long inc1) {
+    // end-of-step bookkeeping rides on the last kernel of the step: advance the Philox counter / batch cursor
+    // (nothing in this kernel reads them)
+    if (state && blockIdx.x == 0 && threadIdx.x == 0) { state[0] += inc0; state[1] += inc1; }
     const long stride = (long)gridDim.x * blockDim.x * 4;
     for (long i = ((long)blockIdx.x * blockDim.x + threadIdx.x) * 4; i < n; i += stride) {
         if (i + 3 < n) {
@@ -327,6 +336,55 @@ __global__ void bn_stats_kernel(const float* __restrict__ P, int ns, long ss, in
         }
     q = rg_reduce(q, red);
     if (ok && rg == 0) { mean[n] = mu; m2[n] = q; }
+}
+
+// Single-rank form: statistics + normalise + ReLU + running-stat update in one launch (same arithmetic as
+// bn_stats followed by bn_apply_relu).
+__global__ void bn_train_relu_kernel(const float* __restrict__ P, int ns, long ss, int ldp, int M, int N,
+                                     const float* __restrict__ bias, float eps, const float* __restrict__ gamma,
+                                     const float* __restrict__ beta, float* __restrict__ XH, float* __restrict__ H,
+                                     int ldo, float* __restrict__ mean, float* __restrict__ m2,
+                                     float* __restrict__ invstd_out, float* __restrict__ rmean,
+                                     float* __restrict__ rvar, float momentum, int nupd) {
+    __shared__ float red[RG][CT];
+    const int n = blockIdx.x * CT + threadIdx.x, rg = threadIdx.y;
+    const bool ok = n < N;
+    const float b = ok && bias ? bias[n] : 0.f;
+    float s = 0.f;
+    if (ok)
+        for (int m = rg; m < M; m += RG) {
+            const float z = slab_sum(P, ns, ss, (long)m * ldp + n) + b;
+            XH[(long)m * ldo + n] = z;            // parked; each thread re-reads only what it wrote
+            s += z;
+        }
+    const float mu = rg_reduce(s, red) / (float)M;
+    float q = 0.f;
+    if (ok)
+        for (int m = rg; m < M; m += RG) {
+            const float d = XH[(long)m * ldo + n] - mu;
+            q = __fmaf_rn(d, d, q);
+        }
+    q = rg_reduce(q, red);
+    if (!ok) return;
+    const float istd = 1.0f / sqrtf(q / (float)M + eps);
+    const float ga = gamma[n], be = beta[n];
+    for (int m = rg; m < M; m += RG) {
+        const float xh = (XH[(long)m * ldo + n] - mu) * istd;
+        XH[(long)m * ldo + n] = xh;
+        H[(long)m * ldo + n] = fmaxf(__fmaf_rn(xh, ga, be), 0.f);
+    }
+    if (rg == 0) {
+        mean[n] = mu; m2[n] = q; invstd_out[n] = istd;
+        if (rmean) {
+            const float uv = q / ((float)M - 1.f);
+            float rm = rmean[n], rv = rvar[n];
+            for (int u = 0; u < nupd; ++u) {
+                rm = (1.f - momentum) * rm + momentum * mu;
+                rv = (1.f - momentum) * rv + momentum * uv;
+            }
+            rmean[n] = rm; rvar[n] = rv;
+        }
+    }
 }
 
 // apply: var = m2 / count (biased); xhat = (z - mean) * rsqrt(var + eps); h = relu(gamma * xhat + beta).
@@ -595,14 +653,14 @@ int wfd_colsum_multi(const long long* desc, int nseg, int total_blocks, void* st
 }
 
 int wfd_rmsprop(float* p, const float* g, float* sq, long n, float lr, float alpha, float eps, float gscale,
-                void* stream) {
+                unsigned long long* state, unsigned long long inc0, unsigned long long inc1, void* stream) {
     if (!p || !g || !sq || n <= 0) return WFD_ERR_ARG;
     if ((((uintptr_t)p | (uintptr_t)g | (uintptr_t)sq) & 15) != 0) return WFD_ERR_ARG;
     long blocks = (n / 4 + 255) / 256;
     if (blocks > 2048) blocks = 2048;
     if (blocks < 1) blocks = 1;
     hipLaunchKernelGGL(rmsprop_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, p, g, sq, n, lr, alpha,
-                       eps, gscale);
+                       eps, gscale, state, inc0, inc1);
     WFD_CHECK_LAUNCH();
     return WFD_OK;
 }
@@ -612,6 +670,16 @@ int wfd_bn_stats(const float* P, int ns, long ss, int ldp, int M, int N, const f
     if (!P || !Z || !mean || !m2) return WFD_ERR_ARG;
     hipLaunchKernelGGL(bn_stats_kernel, dim3(cdiv(N, CT)), dim3(CT, RG), 0, (hipStream_t)stream, P, ns, ss, ldp, M, N,
                        bias, Z, ldz, mean, m2);
+    WFD_CHECK_LAUNCH();
+    return WFD_OK;
+}
+
+int wfd_bn_train_relu(const float* P, int ns, long ss, int ldp, int M, int N, const float* bias, float eps,
+                      const float* gamma, const float* beta, float* XH, float* H, int ldo, float* mean, float* m2,
+                      float* invstd, float* rmean, float* rvar, float momentum, int nupd, void* stream) {
+    if (!P || !gamma || !beta || !XH || !H || !mean || !m2 || !invstd || M < 2) return WFD_ERR_ARG;
+    hipLaunchKernelGGL(bn_train_relu_kernel, dim3(cdiv(N, CT)), dim3(CT, RG), 0, (hipStream_t)stream, P, ns, ss, ldp, M,
+                       N, bias, eps, gamma, beta, XH, H, ldo, mean, m2, invstd, rmean, rvar, momentum, nupd);
     WFD_CHECK_LAUNCH();
     return WFD_OK;
 }

@@ -83,6 +83,43 @@ __global__ void gather_batch_kernel(const float* __restrict__ X, int ldX, const 
     if (threadIdx.x == 0 && labels_out) labels_out[b] = lab;
 }
 
+// z rows and the dropout keep-masks of one step in a single launch (same streams as the two kernels above:
+// blocks [0, zblocks) draw the normals, the rest the masks)
+__global__ void rng_step_inputs_kernel(float* __restrict__ zout, int ld, int M, int Z, unsigned long long zseed,
+                                       float* __restrict__ mout, long nmask, float p, unsigned long long mseed,
+                                       const unsigned long long* __restrict__ state, int zblocks) {
+    const unsigned long long offset = state ? state[0] : 0ull;
+    if ((int)blockIdx.x < zblocks) {
+        const long total4 = ((long)M * Z + 3) / 4;
+        for (long q = (long)blockIdx.x * blockDim.x + threadIdx.x; q < total4; q += (long)zblocks * blockDim.x) {
+            const unsigned long long c = offset + (unsigned long long)q;
+            const uint4 r = philox4x32_10(make_uint4((uint32_t)c, (uint32_t)(c >> 32), 0x6e6f726du, 0u),
+                                          make_uint2((uint32_t)zseed, (uint32_t)(zseed >> 32)));
+            const float r0 = sqrtf(-2.f * logf(u01(r.x))), r1 = sqrtf(-2.f * logf(u01(r.z)));
+            float s0, c0, s1, c1;
+            sincosf(6.283185307179586f * u01(r.y), &s0, &c0);
+            sincosf(6.283185307179586f * u01(r.w), &s1, &c1);
+            const float v[4] = {r0 * c0, r0 * s0, r1 * c1, r1 * s1};
+            for (int k = 0; k < 4; ++k) {
+                const long e = q * 4 + k;
+                if (e < (long)M * Z) zout[(e / Z) * ld + (e % Z)] = v[k];
+            }
+        }
+    } else {
+        const float keep = 1.0f / (1.0f - p);
+        const long nb = (long)gridDim.x - zblocks;
+        for (long q = ((long)blockIdx.x - zblocks) * blockDim.x + threadIdx.x; q * 4 < nmask; q += nb * blockDim.x) {
+            const unsigned long long c = offset + (unsigned long long)q;
+            const uint4 r = philox4x32_10(make_uint4((uint32_t)c, (uint32_t)(c >> 32), 0x6d61736bu, 0u),
+                                          make_uint2((uint32_t)mseed, (uint32_t)(mseed >> 32)));
+            const float v[4] = {u01(r.x) >= p ? keep : 0.f, u01(r.y) >= p ? keep : 0.f, u01(r.z) >= p ? keep : 0.f,
+                                u01(r.w) >= p ? keep : 0.f};
+            for (int k = 0; k < 4; ++k)
+                if (q * 4 + k < nmask) mout[q * 4 + k] = v[k];
+        }
+    }
+}
+
 // U[0,1) row weights (np.random.random((B,1)), src/utils.py:67)
 __global__ void rng_uniform_kernel(float* __restrict__ out, long n, unsigned long long seed,
                                    const unsigned long long* __restrict__ state, unsigned long long base) {
@@ -205,6 +242,19 @@ int wfd_gather_batch(const float* X, int ldX, const int* y, const long long* idx
     if (!X || !y || !idx || !real || B <= 0 || n_idx <= 0 || n_rows <= 0) return WFD_ERR_ARG;
     hipLaunchKernelGGL(gather_batch_kernel, dim3(B), dim3(256), 0, (hipStream_t)stream, X, ldX, y, idx, state, n_idx, n_rows,
                        S, C, real, fake, ldd, zin, ldz, Z, labels_out);
+    WFD_CHECK_LAUNCH();
+    return WFD_OK;
+}
+
+int wfd_rng_step_inputs(float* zout, int ld, int M, int Z, unsigned long long zseed, float* mout, long nmask, float p,
+                        unsigned long long mseed, const unsigned long long* state, void* stream) {
+    if (!zout || !mout || M <= 0 || Z <= 0 || ld < Z || nmask <= 0 || p < 0.f || p >= 1.f) return WFD_ERR_ARG;
+    long zb = (((long)M * Z + 3) / 4 + 255) / 256, mb = (nmask / 4 + 255) / 256;
+    if (zb > 256) zb = 256;
+    if (mb > 2048) mb = 2048;
+    if (mb < 1) mb = 1;
+    hipLaunchKernelGGL(rng_step_inputs_kernel, dim3((unsigned)(zb + mb)), dim3(256), 0, (hipStream_t)stream, zout, ld, M,
+                       Z, zseed, mout, nmask, p, mseed, state, (int)zb);
     WFD_CHECK_LAUNCH();
     return WFD_OK;
 }

@@ -156,7 +156,7 @@ class TrainEngine:
                  DF_state: Dict[str, torch.Tensor], lr: float = 2e-4, alpha: float = 0.02, n_critic: int = 3,
                  penalty: str = "div", lambda_gp: float = 10.0, device="cuda:0", global_batch: Optional[int] = None,
                  seed: int = 0, workspace_mb: int = 256, process_group=None, world_size: int = 1,
-                 share: Optional["TrainEngine"] = None):
+                 share: Optional["TrainEngine"] = None, overlap: bool = False):
         if not torch.cuda.is_available():
             raise RuntimeError("wfd_gan_amd.TrainEngine needs a HIP device: there is no CPU path")
         if penalty not in ("div", "gp"):
@@ -217,6 +217,8 @@ class TrainEngine:
         b["H3"], b["T3"] = z(M, 512), z(M, 512)
         b["V"], b["NSQ"], b["PEN"], b["DV"], b["PENFLAG"] = z(M), z(M), z(M), z(M), z(M)
         b["GPA"] = z(B)                  # WGAN-GP interpolation weights alpha (B,1)
+        for nme in ("NDV", "PW", "INVB", "RSELR", "RSELF"):
+            b[nme] = z(M)                # constant row weights that turn the loss scalars into column sums
         b["dstats"], b["gstats"], b["ghead"] = z(8), z(8), z(2)
         b["dacc"] = share.buf["dacc"] if share is not None else z(4)      # epoch sums live on device
         b["gacc"] = share.buf["gacc"] if share is not None else z(4)
@@ -251,7 +253,10 @@ class TrainEngine:
         self.ldl = rup(S - 1, 4)
         b["DDF"] = z(B, self.ldl)
         b["ws"] = torch.empty(workspace_mb * (1 << 18), **f32)
+        b["ws2"] = torch.empty(64 * (1 << 18), **f32)        # slab workspace of the side lane
+        self.overlap = overlap
 
+        self.iter_state = torch.zeros(2, dtype=torch.int64, device=dev)   # [philox counter, perm cursor]
         self._fill_row_constants()
         self.plan_d = self._build_d_plan()
         self.plan_g = self._build_g_plan()
@@ -282,6 +287,15 @@ class TrainEngine:
             flag[2 * B:] = 1.0
         b["DV"].copy_(dv)
         b["PENFLAG"].copy_(flag)
+        b["NDV"].copy_(-dv)
+        b["PW"].fill_((1.0 if self.penalty == "div" else self.lambda_gp) / self.Bg)
+        b["INVB"].fill_(1.0 / self.Bg)
+        sel = torch.zeros(self.M)
+        sel[:B] = 1.0 / self.Bg
+        b["RSELR"].copy_(sel)
+        sel = torch.zeros(self.M)
+        sel[B:2 * B] = 1.0 / self.Bg
+        b["RSELF"].copy_(sel)
 
     # ------------------------------------------------------------------------------------------------------
     def _g_forward(self, p: Plan, nupd: int):
@@ -292,6 +306,13 @@ class TrainEngine:
         prev, kprev = b["GH1"], 512
         for i, lin, bn, n in ((2, "model.2", "model.3", 1024), (3, "model.5", "model.6", 2048)):
             s = p.gemm(NT, prev, kprev, G[f"{lin}.weight"], kprev, B, n, kprev)
+            if self.world == 1:
+                p.add(self.L.bn_train_relu, s.ptr, s.ns, s.ss, s.ldp, B, n, ptr(G[f"{lin}.bias"]), 0.8,
+                      ptr(G[f"{bn}.weight"]), ptr(G[f"{bn}.bias"]), ptr(b[f"GXH{i}"]), ptr(b[f"GH{i}"]), n,
+                      ptr(b[f"mean{i}"]), ptr(b[f"m2{i}"]), ptr(b[f"istd{i}"]), ptr(self.Gbuf[f"{bn}.running_mean"]),
+                      ptr(self.Gbuf[f"{bn}.running_var"]), 0.1, nupd)
+                prev, kprev = b[f"GH{i}"], n
+                continue
             p.add(self.L.bn_stats, s.ptr, s.ns, s.ss, s.ldp, B, n, ptr(G[f"{lin}.bias"]), ptr(b[f"GZ{i}"]), n,
                   ptr(b[f"mean{i}"]), ptr(b[f"m2{i}"]))
             self._bn_sync_hook(p, i)
@@ -329,9 +350,25 @@ class TrainEngine:
         p.mul(s, D1, 2048, DM_MUL, None, rowscale, DL1, DL1s, 2048)
         return p.gemm(NN, DL1, 2048, D["model.0.weight"], S + C, M, S, 2048)
 
-    def _build_d_plan(self) -> Plan:
-        B, M, S, C, b, D = self.B, self.M, self.S, self.C, self.buf, self.Dp
-        p = Plan(b["ws"])
+    GOLD = 0x9E3779B97F4A7C15
+
+    def _rng_inc(self) -> int:
+        return max((self.B * self.Z + 3) // 4, (self.buf["MKflat"].numel() + 3) // 4)
+
+    def _build_d_plan(self, fast: bool = False) -> Plan:
+        """fast: the batch, z and the dropout masks are produced on device from the resident dataset / Philox and
+        the step ends by advancing the device-resident iteration state (graph-replayable); otherwise the caller
+        supplies them (parity mode)."""
+        B, M, S, C, Z, b, D = self.B, self.M, self.S, self.C, self.Z, self.buf, self.Dp
+        p = Plan(b["ws"], b["ws2"], self.overlap)
+        st = self.iter_state.data_ptr()
+        if fast:
+            p.add(self.L.gather_batch, ptr(self.data_X), S, ptr(self.data_y), ptr(self.perm), st, self.N, self.N, B, S,
+                  C, ptr(self.real_rows), ptr(self.fake_rows), self.ldx, ptr(b["ZIN"]), self.ldz, Z, ptr(b["labels"]))
+            p.add(self.L.rng_step_inputs, ptr(b["ZIN"]), self.ldz, B, Z, (self.seed + 7 * self.GOLD) & (2**64 - 1),
+                  ptr(b["MKflat"]), b["MKflat"].numel(), 0.2, (self.seed + self.GOLD) & (2**64 - 1), st)
+            if self.penalty == "gp":
+                p.add(self.L.rng_uniform, ptr(b["GPA"]), B, (self.seed + 11 * self.GOLD) & (2**64 - 1), st, 0)
         self._g_forward(p, nupd=1)
         if self.penalty == "gp":
             # interpolates = third row group of the critic input (src/utils.py:67-69)
@@ -346,35 +383,51 @@ class TrainEngine:
         mode = 0 if self.penalty == "div" else 1
         p.add(self.L.ep_penalty_row, g.ptr, g.ns, g.ss, g.ldp, M, S, mode, 1.0 / self.Bg, self.lambda_gp,
               ptr(b["PENFLAG"]), ptr(b["NSQ"]), ptr(b["PEN"]), ptr(b["XC"]), self.ldx)
-        p.add(self.L.d_loss, ptr(b["V"]), ptr(b["PEN"]), B, M, 1.0 / self.Bg,
-              1.0 if self.penalty == "div" else self.lambda_gp, ptr(b["dstats"]), ptr(b["dacc"]))
-        # t-chain (second-order part of d_loss.backward())
+        # t-chain (second-order part of d_loss.backward()) on the main lane; each layer's weight gradient (one TN
+        # product over the stacked [penalty ; standard] rows) runs beside it on the side lane as soon as its
+        # operands exist
         Dp = D.p
+        p.fork()
+        with p.side():
+            p.gemm(TN, b["DL1"], 2048, b["XC"], self.ldx, 2048, S + C, 2 * M, out=D.g["model.0.weight"], ldp=S + C)
         s = p.gemm(NT, b["XC"], self.ldx, Dp["model.0.weight"], S + C, M, 2048, S)
         p.mul(s, b["D1"], 2048, DM_MUL, None, None, b["T1H1"][:M], None, 2048)
+        p.fork()
+        with p.side():
+            p.gemm(TN, b["DL2"], 1024, b["T1H1"], 2048, 1024, 2048, 2 * M, out=D.g["model.3.weight"], ldp=2048)
         s = p.gemm(NT, b["T1H1"][:M], 2048, Dp["model.3.weight"], 2048, M, 1024, 2048)
         p.mul(s, b["D2"], 1024, DM_MUL, None, None, b["T2H2"][:M], None, 1024)
+        p.fork()
+        with p.side():
+            p.gemm(TN, b["DL3"], 512, b["T2H2"], 1024, 512, 1024, 2 * M, out=D.g["model.6.weight"], ldp=1024)
         s = p.gemm(NT, b["T2H2"][:M], 1024, Dp["model.6.weight"], 1024, M, 512, 1024)
         p.mul(s, b["D3"], 512, DM_MUL, None, None, b["T3"], None, 512)
-        # weight gradients: one TN product per layer over the stacked [penalty ; standard] rows
-        p.gemm(TN, b["DL1"], 2048, b["XC"], self.ldx, 2048, S + C, 2 * M, out=D.g["model.0.weight"], ldp=S + C)
-        p.gemm(TN, b["DL2"], 1024, b["T1H1"], 2048, 1024, 2048, 2 * M, out=D.g["model.3.weight"], ldp=2048)
-        p.gemm(TN, b["DL3"], 512, b["T2H2"], 1024, 512, 1024, 2 * M, out=D.g["model.6.weight"], ldp=1024)
         self._colsum_multi(p, "d_small", [
             (b["DL1"][M:], 2048, None, None, 0, None, M, 2048, D.g["model.0.bias"]),
             (b["DL2"][M:], 1024, None, None, 0, None, M, 1024, D.g["model.3.bias"]),
             (b["DL3"][M:], 512, None, None, 0, None, M, 512, D.g["model.6.bias"]),
             (b["T3"], 512, None, b["H3"], 512, b["DV"], M, 512, D.g["model.9.weight"]),
-            (b["DV"], 1, None, None, 0, None, M, 1, D.g["model.9.bias"])])
+            (b["DV"], 1, None, None, 0, None, M, 1, D.g["model.9.bias"]),
+            # loss scalars of :215-227 as weighted column sums of the per-row critic scores / penalties:
+            # dstats = [d_loss, penalty, w_dist, mean_rv, mean_fv]; dacc += [d_loss, w_dist] (epoch sums)
+            (b["V"], 1, b["DV"], b["PEN"], 1, b["PW"], M, 1, b["dstats"][0:1], b["dacc"][0:1]),
+            (b["PEN"], 1, b["INVB"], None, 0, None, M, 1, b["dstats"][1:2]),
+            (b["V"], 1, b["NDV"], None, 0, None, M, 1, b["dstats"][2:3], b["dacc"][1:2]),
+            (b["V"], 1, b["RSELR"], None, 0, None, M, 1, b["dstats"][3:4]),
+            (b["V"], 1, b["RSELF"], None, 0, None, M, 1, b["dstats"][4:5])])
+        p.join()
         self._grad_sync_hook(p, "D")
-        p.add(self.L.rmsprop, ptr(D.flat), ptr(D.grad), ptr(D.sq), D.numel, self.lr, 0.99, 1e-8, 1.0 / self.world)
+        p.add(self.L.rmsprop, ptr(D.flat), ptr(D.grad), ptr(D.sq), D.numel, self.lr, 0.99, 1e-8, 1.0 / self.world,
+              st if fast else 0, self._rng_inc() if fast else 0, B if fast else 0)
         return p
 
     def _colsum_multi(self, p: Plan, name: str, segs):
         """segs: (X, ldx, rowscale, X2, ldx2, rowscale2, M, N, out) -> one launch of wfd_colsum_multi."""
         rows, blk = [], 0
-        for X, ldx, rs, X2, ldx2, rs2, M, N, out in segs:
-            rows.append([ptr(X), ldx, ptr(rs), ptr(X2), ldx2, ptr(rs2), M, N, ptr(out), blk])
+        for sg in segs:
+            X, ldx, rs, X2, ldx2, rs2, M, N, out = sg[:9]
+            acc = sg[9] if len(sg) > 9 else None
+            rows.append([ptr(X), ldx, ptr(rs), ptr(X2), ldx2, ptr(rs2), M, N, ptr(out), blk, ptr(acc)])
             blk += (N + 31) // 32
         desc = torch.tensor(rows, dtype=torch.int64, device=self.dev)
         self.buf["desc_" + name] = desc
@@ -393,6 +446,7 @@ class TrainEngine:
         cv = df.convs
         kin = 256 * Ls[4]
         observer_forward(p, df, self.fake_rows, self.ldx, 1, B, Y, PO, b["F1"], b["F2"], b["LOG"], self.ldc)
+        p.join()                       # critic scores of the fake rows (side lane) are needed from here on
         self._nsel_sync_hook(p)
         p.add(self.L.masked_ce, ptr(b["LOG"]), self.ldc, B, self.C, ptr(b["labels"]), ptr(b["gV"]),
               b["ghead"].data_ptr() + 4, self.alpha, ptr(b["CE"]), ptr(b["DLOG"]), self.ldc)
@@ -427,38 +481,52 @@ class TrainEngine:
     def _nsel_sync_hook(self, p: Plan):
         return
 
-    def _build_g_plan(self) -> Plan:
+    def _build_g_plan(self, fast: bool = False) -> Plan:
         B, S, C, Z, b, G = self.B, self.S, self.C, self.Z, self.buf, self.Gp
-        p = Plan(b["ws"])
+        p = Plan(b["ws"], b["ws2"], self.overlap)
+        st = self.iter_state.data_ptr()
+        if fast:
+            t = b["gMKflat"]
+            p.add(self.L.rng_dropout_mask, ptr(t), t.numel(), 0.2, (self.seed + 4 * self.GOLD) & (2**64 - 1), st, 0)
         # The generator parameters and z are unchanged since the D-step's forward, so the second
         # generator(z, c) of :240 reproduces the same activations; only its BN running-stat update is new.
         for i, bn, n in ((2, "model.3", 1024), (3, "model.6", 2048)):
             p.add(self.L.bn_running_update, ptr(b[f"mean{i}"]), ptr(b[f"m2{i}"]), float(self.Bg), n,
                   ptr(self.Gbuf[f"{bn}.running_mean"]), ptr(self.Gbuf[f"{bn}.running_var"]), 0.1, 1)
-        self._critic_forward(p, self.fake_rows, B, (b["gMK1"], b["gMK2"], b["gMK3"]), b["gH1"], b["gH2"], b["gH3"],
-                             b["gD1"], b["gD2"], b["gD3"], b["gV"], b["gDL3"], None, None)
-        p.add(self.L.g_head, ptr(b["gV"]), B, 1.0 / self.Bg, ptr(b["ghead"]))
+        # side lane: critic pass on the fake rows + its input-gradient chain (slabs stay in the side workspace until
+        # g_out_bwd reads them); main lane: the DF observer forward.  They meet at the masked CE.
+        p.fork()
+        with p.side():
+            self._critic_forward(p, self.fake_rows, B, (b["gMK1"], b["gMK2"], b["gMK3"]), b["gH1"], b["gH2"],
+                                 b["gH3"], b["gD1"], b["gD2"], b["gD3"], b["gV"], b["gDL3"], None, None)
+            p.add(self.L.g_head, ptr(b["gV"]), B, 1.0 / self.Bg, ptr(b["ghead"]))
+            g = self._critic_chain(p, B, b["gDL3"], b["gDL2"], None, b["gDL1"], None, b["gD2"], b["gD1"], None)
         self._observer(p)
-        g = self._critic_chain(p, B, b["gDL3"], b["gDL2"], None, b["gDL1"], None, b["gD2"], b["gD1"], None)
         p.add(self.L.g_out_bwd, g.ptr, g.ns, g.ss, g.ldp, B, S, -1.0 / self.Bg, ptr(b["DDF"]), self.ldl,
               ptr(self.fake_rows), self.ldx, ptr(b["idx"]), ptr(b["GDZ4"]), self.lds4, ptr(G.g["model.8.bias"]))
-        # generator backward
+        # generator backward: the activation-gradient chain on the main lane, each weight gradient on the side lane
         Gp = G.p
-        p.gemm(TN, b["GDZ4"], self.lds4, b["GH3"], 2048, S, 2048, B, out=G.g["model.8.weight"], ldp=2048)
+        p.fork()
+        with p.side():
+            p.gemm(TN, b["GDZ4"], self.lds4, b["GH3"], 2048, S, 2048, B, out=G.g["model.8.weight"], ldp=2048)
         prev_dz, kdz, wkey = b["GDZ4"], S, "model.8.weight"
         lddz = self.lds4
         for i, lin, bn, n, hin, kin in ((3, "model.5", "model.6", 2048, b["GH2"], 1024),
                                         (2, "model.2", "model.3", 1024, b["GH1"], 512)):
             s = p.gemm(NN, prev_dz, lddz, Gp[wkey], n, B, n, kdz)
             self._bn_bwd(p, s, i, lin, bn, n)
-            p.gemm(TN, b[f"GDZ{i}"], n, hin, kin, n, kin, B, out=G.g[f"{lin}.weight"], ldp=kin)
+            p.fork()
+            with p.side():
+                p.gemm(TN, b[f"GDZ{i}"], n, hin, kin, n, kin, B, out=G.g[f"{lin}.weight"], ldp=kin)
             prev_dz, kdz, wkey, lddz = b[f"GDZ{i}"], n, f"{lin}.weight", n
         s = p.gemm(NN, prev_dz, 1024, Gp["model.2.weight"], 512, B, 512, 1024)
         p.mul(s, b["GH1"], 512, DM_RELU, None, None, b["GDZ1"], None, 512)
         p.add(self.L.colsum, ptr(b["GDZ1"]), 512, B, 512, 0, ptr(G.g["model.0.bias"]), 0)
         p.gemm(TN, b["GDZ1"], 512, b["ZIN"], self.ldz, 512, Z + C, B, out=G.g["model.0.weight"], ldp=Z + C)
+        p.join()
         self._grad_sync_hook(p, "G")
-        p.add(self.L.rmsprop, ptr(G.flat), ptr(G.grad), ptr(G.sq), G.numel, self.lr, 0.99, 1e-8, 1.0 / self.world)
+        p.add(self.L.rmsprop, ptr(G.flat), ptr(G.grad), ptr(G.sq), G.numel, self.lr, 0.99, 1e-8, 1.0 / self.world,
+              st if fast else 0, self._rng_inc() if fast else 0, 0)
         return p
 
     def _bn_bwd(self, p: Plan, s: Slabs, i: int, lin: str, bn: str, n: int):
@@ -561,7 +629,7 @@ class TrainEngine:
         self.iters_per_epoch = self.N // self.B          # full batches; the trainer handles a ragged tail
         self.auto_reshuffle = True                       # iteration() starts a new permutation when one is used up
         self._pos = 0
-        self.iter_state = torch.zeros(2, dtype=torch.int64, device=self.dev)   # [philox counter, perm cursor]
+        self.iter_state.zero_()
         self.perm_gen = torch.Generator(device=self.dev)
         self.perm_gen.manual_seed(shuffle_seed)
         self.perm = torch.randperm(self.N, generator=self.perm_gen, device=self.dev)
@@ -574,26 +642,7 @@ class TrainEngine:
         self._pos = 0
 
     def _build_fast_plans(self):
-        B, S, C, Z, b = self.B, self.S, self.C, self.Z, self.buf
-        st = self.iter_state.data_ptr()
-        gold = 0x9E3779B97F4A7C15
-        pd = Plan(b["ws"])
-        pd.add(self.L.gather_batch, ptr(self.data_X), S, ptr(self.data_y), ptr(self.perm), st, self.N, self.N, B, S, C,
-               ptr(self.real_rows), ptr(self.fake_rows), self.ldx, ptr(b["ZIN"]), self.ldz, Z, ptr(b["labels"]))
-        pd.add(self.L.rng_normal_rows, ptr(b["ZIN"]), self.ldz, B, Z, (self.seed + 7 * gold) & (2**64 - 1), st, 0)
-        t = b["MKflat"]
-        pd.add(self.L.rng_dropout_mask, ptr(t), t.numel(), 0.2, (self.seed + gold) & (2**64 - 1), st, 0)
-        inc = max((B * Z + 3) // 4, (t.numel() + 3) // 4)
-        if self.penalty == "gp":
-            pd.add(self.L.rng_uniform, ptr(b["GPA"]), B, (self.seed + 11 * gold) & (2**64 - 1), st, 0)
-        pd.calls += self.plan_d.calls
-        pd.add(self.L.iter_advance, st, inc, B)
-        pg = Plan(b["ws"])
-        t = b["gMKflat"]
-        pg.add(self.L.rng_dropout_mask, ptr(t), t.numel(), 0.2, (self.seed + 4 * gold) & (2**64 - 1), st, 0)
-        pg.calls += self.plan_g.calls
-        pg.add(self.L.iter_advance, st, inc, 0)
-        return pd, pg
+        return self._build_d_plan(fast=True), self._build_g_plan(fast=True)
 
     def _snapshot(self):
         snap = dict(G=self.Gp.flat.clone(), Gsq=self.Gp.sq.clone(), D=self.Dp.flat.clone(), Dsq=self.Dp.sq.clone(),

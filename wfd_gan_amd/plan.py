@@ -17,6 +17,8 @@ Slabs = namedtuple("Slabs", "ptr ns ss ldp M N")
 
 NT, NN, TN = 0, 1, 2
 HOST = object()          # marker: plan entry executed on the host (e.g. a torch.distributed collective)
+FORK = object()          # marker: the side stream waits for everything launched on the main stream so far
+JOIN = object()          # marker: the main stream waits for the side stream
 ACT_NONE, ACT_RELU, ACT_ELU, ACT_SIGMOID = 0, 1, 2, 3
 DM_NONE, DM_MUL, DM_RELU, DM_ELU = 0, 1, 2, 3
 
@@ -34,44 +36,100 @@ def rup(x: int, m: int) -> int:
 
 
 class Plan:
-    """Accumulates (function, args) pairs; ``run(stream)`` launches them in order."""
+    """Accumulates (function, args, lane) triples; ``run()`` launches them in order.
 
-    def __init__(self, workspace: torch.Tensor):
+    Lane 0 is the caller's current stream, lane 1 a side stream: independent branches of a step (weight-gradient
+    GEMMs next to the backward chain, the DF observer next to the critic pass) are issued on the side lane between
+    ``fork()`` / ``join()`` markers, so that small kernels which cannot fill 256 CUs on their own overlap.  Under
+    HIP-graph capture the same markers become graph dependencies.  Each lane has its own slab workspace."""
+
+    _side_streams = {}
+
+    def __init__(self, workspace: torch.Tensor, side_workspace: Optional[torch.Tensor] = None, overlap: bool = True):
         self.L = lib()
-        self.ws = workspace            # fp32 scratch for split-K slabs
-        self.ws_floats = workspace.numel()
+        self.two = side_workspace is not None          # side lane available (own slab workspace)
+        self.ws_lane = [workspace, side_workspace if self.two else workspace]
         self.calls: List[Tuple] = []
-        self.keep = []                 # tensors referenced by raw pointer
+        self.lane = 0
+        self.overlap = self.two and overlap            # side lane on its own stream (else: same stream, in order)
+
+    @property
+    def ws(self):
+        return self.ws_lane[self.lane]
+
+    @property
+    def ws_floats(self):
+        return self.ws_lane[self.lane].numel()
 
     # -- generic ------------------------------------------------------------------------------------------
     def add(self, fn, *args):
-        self.calls.append((fn, args))
+        self.calls.append((fn, args, self.lane))
+
+    def extend(self, other: "Plan"):
+        self.calls += other.calls
 
     def host(self, thunk):
         """A host-side action between launches (a collective): splits the plan into separately captured stages."""
-        self.calls.append((HOST, (thunk,)))
+        self.calls.append((HOST, (thunk,), 0))
 
-    def run(self, stream: Optional[int] = None):
-        if stream is None:
-            stream = torch.cuda.current_stream().cuda_stream
-        for fn, a in self.calls:
-            if fn is HOST:
+    def fork(self):
+        """Following side-lane launches may start once everything issued on the main lane so far is done."""
+        if self.two:
+            self.calls.append((FORK, (), 1))
+
+    def join(self):
+        if self.two:
+            self.calls.append((JOIN, (), 1))
+
+    class _Side:
+        def __init__(self, plan):
+            self.plan = plan
+
+        def __enter__(self):
+            if self.plan.two:
+                self.plan.lane = 1
+
+        def __exit__(self, *exc):
+            self.plan.lane = 0
+
+    def side(self):
+        """``with plan.side(): ...`` issues the enclosed launches on the side lane (no-op without overlap)."""
+        return Plan._Side(self)
+
+    def run(self, serial: bool = False):
+        main = torch.cuda.current_stream()
+        side = None
+        if self.overlap and not serial:
+            key = main.device
+            side = Plan._side_streams.get(key)
+            if side is None:
+                side = Plan._side_streams[key] = torch.cuda.Stream(device=main.device)
+        ms = main.cuda_stream
+        ss = side.cuda_stream if side is not None else ms
+        for fn, a, lane in self.calls:
+            if fn is FORK:
+                if side is not None:
+                    side.wait_stream(main)
+            elif fn is JOIN:
+                if side is not None:
+                    main.wait_stream(side)
+            elif fn is HOST:
                 a[0]()
-                stream = torch.cuda.current_stream().cuda_stream
             else:
-                fn(*a, stream)
+                fn(*a, ss if lane else ms)
 
     def stages(self):
         """[Plan | thunk, ...]: maximal runs of launches separated by host actions."""
-        out, cur = [], Plan(self.ws)
-        for fn, a in self.calls:
+        mk = lambda: Plan(self.ws_lane[0], self.ws_lane[1] if self.two else None, self.overlap)
+        out, cur = [], mk()
+        for fn, a, lane in self.calls:
             if fn is HOST:
                 if len(cur):
                     out.append(cur)
                 out.append(a[0])
-                cur = Plan(self.ws)
+                cur = mk()
             else:
-                cur.calls.append((fn, a))
+                cur.calls.append((fn, a, lane))
         if len(cur):
             out.append(cur)
         return out
