@@ -46,6 +46,14 @@ def _worker(rank, world, port, q):
     dist.all_gather(gathered, local)
     want = sum(gathered) / world
     ok = torch.allclose(flat, want, rtol=0, atol=1e-7)
+    # bucketed asynchronous form used by the engine: two slices of one flat buffer
+    flat2 = local.clone()
+    gs = parallel.GradSync()
+    cut = flat2.numel() // 3
+    gs.start(flat2[:cut])
+    gs.start(flat2[cut:])
+    gs.finish()
+    ok = ok and torch.allclose(flat2 / world, want, rtol=0, atol=1e-7) and not gs.pending
     tmax = parallel.max_over_ranks(float(rank + 1), "cpu")
     tsum = parallel.sum_over_ranks(1.0, "cpu")
     t = torch.full((3,), float(rank))

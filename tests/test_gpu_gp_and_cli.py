@@ -123,6 +123,34 @@ def test_fast_mode_graph_equals_eager():
     assert torch.isfinite(e1.Dp.flat).all() and torch.isfinite(e1.Gp.flat).all()
 
 
+def test_data_parallel_staging_world1_nccl():
+    """The data-parallel code path (split BN kernels, graph stages around the bucketed asynchronous all-reduce over
+    RCCL) with a 1-rank NCCL group must reproduce the single-rank engine bit for bit."""
+    import torch.distributed as dist
+    from wfd_gan_amd.engine import TrainEngine
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29533")
+    if not dist.is_initialized():
+        dist.init_process_group("nccl", rank=0, world_size=1)
+    try:
+        S, C, Z, B = 41, 5, 16, 8
+        st, e1, Xs, y = _setup(S, C, Z, B, "div")
+        e2 = TrainEngine(S, C, Z, B, e1.scaler_min, e1.scaler_max, e1.generator_state(), e1.discriminator_state(),
+                         {k: v for k, v in st.DF.items()}, device=DEV, world_size=1, force_sync=True)
+        for e in (e1, e2):
+            e.attach_dataset(torch.from_numpy(Xs), torch.from_numpy(y), shuffle_seed=5)
+            e.capture_graphs()
+        assert len(e2.graph_d) == 5 and len(e1.graph_d) == 1      # stage, start, stage, start+finish, stage
+        for i in range(7):
+            e1.iteration(i)
+            e2.iteration(i)
+        torch.cuda.synchronize()
+        assert torch.equal(e1.Dp.flat, e2.Dp.flat) and torch.equal(e1.Gp.flat, e2.Gp.flat)
+        assert e1.d_stats() == e2.d_stats()
+    finally:
+        dist.destroy_process_group()
+
+
 def test_trainer_and_sampler_cli(tmp_path):
     from wfd_gan_amd import generate, mlp_df_wgan_train
     n_cls, n_inst, L = 5, 21, 40           # 105 rows, batch 16 -> 6 full batches + ragged tail of 9

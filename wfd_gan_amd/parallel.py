@@ -32,6 +32,24 @@ def allreduce_sum_(flat: torch.Tensor, group=None) -> torch.Tensor:
     return flat
 
 
+class GradSync:
+    """Bucketed gradient all-reduce that overlaps with the rest of the backward: ``start(bucket)`` launches an
+    asynchronous sum over a slice of the flat gradient buffer as soon as that slice is final, ``finish()`` makes
+    the current stream wait for every bucket before the optimizer kernel reads the buffer."""
+
+    def __init__(self, group=None):
+        self.group = group
+        self.pending = []
+
+    def start(self, bucket: torch.Tensor):
+        self.pending.append(dist.all_reduce(bucket, op=dist.ReduceOp.SUM, group=self.group, async_op=True))
+
+    def finish(self):
+        for w in self.pending:
+            w.wait()
+        self.pending.clear()
+
+
 def shard_rows(n_rows: int, rank: int, world: int) -> Tuple[int, int]:
     """Contiguous [begin, end) shard of n_rows for this rank; the first n_rows % world ranks get one extra row."""
     base, rem = divmod(n_rows, world)
