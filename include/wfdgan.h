@@ -41,6 +41,16 @@ int wfd_gemm_f32(int layout, const float* A, int lda, const float* B, int ldb, f
 int wfd_conv8_gemm_f32(const float* X, int Bn, int L, int Cin, int pad, const float* Wp, int Cout, float* P, int ldp,
                        long slab_stride, int splits, void* stream);
 
+/* The same contractions with the consumer's element-wise math fused into the store (single split: no slab round
+ * trip, one launch less): epi 1 = wfd_ep_affine_act (scale/shift/act), epi 2 = wfd_ep_mul (D/dmode/scale, no second
+ * copy).  Used where the product alone fills the chip (DF convs over B*L rows, large-batch Linear layers). */
+int wfd_gemm_f32_fused(int layout, const float* A, int lda, const float* B, int ldb, float* out, int ldo, int M, int N,
+                       int K, int epi, const float* scale, const float* shift, int act, const float* D, int ldd,
+                       int dmode, void* stream);
+int wfd_conv8_gemm_f32_fused(const float* X, int Bn, int L, int Cin, int pad, const float* Wp, int Cout, float* out,
+                             int ldo, int epi, const float* scale, const float* shift, int act, const float* D, int ldd,
+                             int dmode, void* stream);
+
 /* ---- MLP epilogues ------------------------------------------------------------------------------------ */
 
 /* out = act(sumP * scale[n] + shift[n]); act 0 none, 1 ReLU, 2 ELU, 3 sigmoid; scale/shift may be NULL.

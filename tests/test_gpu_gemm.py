@@ -91,3 +91,37 @@ def test_conv8_implicit_gemm(cfg, pad):
     torch.cuda.synchronize()
     out = P.double().sum(0).view(Bn, Ln, Cout).permute(0, 2, 1).cpu()
     assert (out - ref).abs().max().item() / ref.abs().max().item() < 2e-5
+
+
+@pytest.mark.parametrize("shape", [(500, 32, 256), (70, 17, 100), (64, 1, 64), (4096, 32, 64)])
+@pytest.mark.parametrize("layout", [0, 1, 2])
+def test_gemm_narrow_n(layout, shape):
+    """N <= 32 runs the k-split wave arrangement (both wave columns on the same 32 output columns)."""
+    M, N, K = shape
+    assert _run_gemm(layout, M, N, K) < 2e-5
+    assert _run_gemm(layout, M, N, K, splits=1) < 2e-5
+
+
+@pytest.mark.parametrize("N", [32, 64, 100])
+def test_gemm_fused_epilogues(N):
+    from wfd_gan_amd._lib import lib
+    L = lib()
+    g = torch.Generator().manual_seed(3)
+    M, K = 300, 96
+    A, B = torch.randn(M, K, generator=g), torch.randn(N, K, generator=g)
+    scale, shift = torch.rand(N, generator=g) + 0.5, torch.randn(N, generator=g)
+    D = torch.randn(M, N, generator=g)
+    raw = A.double() @ B.double().T
+    Ad, Bd, sd, hd, Dd = (t.to("cuda:0") for t in (A, B, scale, shift, D))
+    out = torch.zeros(M, N, device="cuda:0")
+    st = torch.cuda.current_stream().cuda_stream
+    for act, fn in ((1, torch.relu), (2, torch.nn.functional.elu), (3, torch.sigmoid), (0, lambda x: x)):
+        L.gemm_f32_fused(0, Ad.data_ptr(), K, Bd.data_ptr(), K, out.data_ptr(), N, M, N, K, 1, sd.data_ptr(),
+                         hd.data_ptr(), act, 0, 0, 0, st)
+        want = fn(raw * scale.double() + shift.double())
+        assert (out.cpu().double() - want).abs().max().item() < 1e-4
+    for dmode, f in ((1, lambda r: r * D.double()), (2, lambda r: r * (D > 0)), (3, lambda r: torch.where(D > 0, r, r * (D.double() + 1)))):
+        L.gemm_f32_fused(0, Ad.data_ptr(), K, Bd.data_ptr(), K, out.data_ptr(), N, M, N, K, 2, sd.data_ptr(), 0, 0,
+                         Dd.data_ptr(), N, dmode, st)
+        want = f(raw) * scale.double()
+        assert (out.cpu().double() - want).abs().max().item() < 1e-4

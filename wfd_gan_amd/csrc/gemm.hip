@@ -34,7 +34,32 @@ struct GemmArgs {
     long slab_stride;   // floats between split slabs
     int ktiles_per_split;
     int convL, convCin, convPad;  // IM2COL only
+    int narrow;                   // N <= 32: the two wave columns split each k-tile instead of the N range
+    // fused epilogue (splits == 1 only): 0 raw; 1 out = act(acc*scale[n]+shift[n]); 2 out = acc*f(D[m][n])*scale[n]
+    int epi, act, dmode, ldd;
+    const float* scale;
+    const float* shift;
+    const float* D;
 };
+
+__device__ __forceinline__ float epi_apply(const GemmArgs& g, float v, int row, int col) {
+    if (g.epi == 1) {
+        const float sh = g.shift ? g.shift[col] : 0.f;
+        v = g.scale ? __fmaf_rn(v, g.scale[col], sh) : v + sh;
+        if (g.act == 1) v = fmaxf(v, 0.f);
+        else if (g.act == 2) v = v > 0.f ? v : expm1f(v);
+        else if (g.act == 3) v = 1.0f / (1.0f + expf(-v));
+    } else if (g.epi == 2) {
+        if (g.dmode) {
+            const float d = g.D[(long)row * g.ldd + col];
+            if (g.dmode == 1) v *= d;
+            else if (g.dmode == 2) v = d > 0.f ? v : 0.f;
+            else v = d > 0.f ? v : v * (d + 1.f);
+        }
+        if (g.scale) v *= g.scale[col];
+    }
+    return v;
+}
 
 // ---- global -> register staging -------------------------------------------------------------------------
 // KC = operand is k-contiguous in global memory ([rows][K], ld); else row(k)-major with the m/n index contiguous.
@@ -144,14 +169,18 @@ __device__ __forceinline__ f32x4 read_frag(const float* __restrict__ S, int row0
     }
 }
 
-template <bool AKC, bool BKC, int VA, int VB, bool IM2COL>
+// NARROW / EPI are compile-time so that the plain path keeps its instruction schedule (a runtime branch inside the
+// k-loop made hipcc stop hoisting the next tile's global loads above the MFMA block).
+template <bool AKC, bool BKC, int VA, int VB, bool IM2COL, bool NARROW, bool EPI>
 __global__ __launch_bounds__(NTHREADS) void gemm_f32_kernel(GemmArgs g) {
     __shared__ __attribute__((aligned(16))) float lds[4 * TILE_F];
     // buffer c: A tile at lds + 2c*TILE_F, B tile right behind it
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1, i = lane & 31, h = lane >> 5;
-    const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN, z = blockIdx.z;
+    const int m0 = blockIdx.y * BM, n0 = blockIdx.x * (NARROW ? 32 : BN), z = blockIdx.z;
+    // narrow: wave column index = half of the k-tile it multiplies (kk 0-1 / 2-3), both on columns n0..n0+31
+    const int bcol0 = NARROW ? 0 : wn * 32;
     const int kbeg = z * g.ktiles_per_split * BK;
     const int kend = min(g.K, kbeg + g.ktiles_per_split * BK);
     const int nk = (kend > kbeg) ? (kend - kbeg + BK - 1) / BK : 0;
@@ -178,12 +207,22 @@ __global__ __launch_bounds__(NTHREADS) void gemm_f32_kernel(GemmArgs g) {
         }
         const float* a_s = lds + cur * 2 * TILE_F;
         const float* b_s = a_s + TILE_F;
+        if constexpr (!NARROW) {
 #pragma unroll
-        for (int kk = 0; kk < 4; ++kk) {
-            const f32x4 a = read_frag<AKC>(a_s, wm * 32, kk, i, h);
-            const f32x4 b = read_frag<BKC>(b_s, wn * 32, kk, i, h);
+            for (int kk = 0; kk < 4; ++kk) {
+                const f32x4 a = read_frag<AKC>(a_s, wm * 32, kk, i, h);
+                const f32x4 b = read_frag<BKC>(b_s, wn * 32, kk, i, h);
 #pragma unroll
-            for (int s = 0; s < 4; ++s) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[s], b[s], acc, 0, 0, 0);
+                for (int s = 0; s < 4; ++s) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[s], b[s], acc, 0, 0, 0);
+            }
+        } else {
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const f32x4 a = read_frag<AKC>(a_s, wm * 32, 2 * wn + j, i, h);
+                const f32x4 b = read_frag<BKC>(b_s, 0, 2 * wn + j, i, h);
+#pragma unroll
+                for (int s = 0; s < 4; ++s) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[s], b[s], acc, 0, 0, 0);
+            }
         }
         if (more) {
             store_tile<AKC, VA>(ra, lds + (cur ^ 1) * 2 * TILE_F, tid);
@@ -195,25 +234,50 @@ __global__ __launch_bounds__(NTHREADS) void gemm_f32_kernel(GemmArgs g) {
 
     // C/D map of the 32x32 accumulator: col = lane & 31, row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)
     float* P = g.P + (long)z * g.slab_stride;
-    const int col = n0 + wn * 32 + i;
+    if constexpr (NARROW) {
+        // fold the two k-halves: waves with wn = 1 park their accumulator in LDS, wn = 0 adds and stores
+        float* red = lds + wm * (16 * 64);
+        if (wn == 1) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) red[r * 64 + lane] = acc[r];
+        }
+        __syncthreads();
+        if (wn == 1) return;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[r] += red[r * 64 + lane];
+    }
+    const int col = n0 + bcol0 + i;
     if (col < g.N) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const int row = m0 + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
-            if (row < g.M) P[(long)row * g.ldp + col] = acc[r];
+            if (row < g.M) {
+                if constexpr (EPI) P[(long)row * g.ldp + col] = epi_apply(g, acc[r], row, col);
+                else P[(long)row * g.ldp + col] = acc[r];
+            }
         }
     }
 }
 
-template <bool AKC, bool BKC, bool IM2COL>
-int launch_gemm(const GemmArgs& g, int splits, bool va4, bool vb4, hipStream_t st) {
-    dim3 grid(cdiv(g.N, BN), cdiv(g.M, BM), splits), block(NTHREADS);
-    if (va4 && vb4) hipLaunchKernelGGL((gemm_f32_kernel<AKC, BKC, 4, 4, IM2COL>), grid, block, 0, st, g);
-    else if (va4) hipLaunchKernelGGL((gemm_f32_kernel<AKC, BKC, 4, 1, IM2COL>), grid, block, 0, st, g);
-    else if (vb4) hipLaunchKernelGGL((gemm_f32_kernel<AKC, BKC, 1, 4, IM2COL>), grid, block, 0, st, g);
-    else hipLaunchKernelGGL((gemm_f32_kernel<AKC, BKC, 1, 1, IM2COL>), grid, block, 0, st, g);
+template <bool AKC, bool BKC, bool IM2COL, bool NARROW, bool EPI>
+int launch_gemm2(const GemmArgs& g, int splits, bool va4, bool vb4, hipStream_t st) {
+    dim3 grid(NARROW ? cdiv(g.N, 32) : cdiv(g.N, BN), cdiv(g.M, BM), splits), block(NTHREADS);
+    if (va4 && vb4) hipLaunchKernelGGL((gemm_f32_kernel<AKC, BKC, 4, 4, IM2COL, NARROW, EPI>), grid, block, 0, st, g);
+    else if (va4) hipLaunchKernelGGL((gemm_f32_kernel<AKC, BKC, 4, 1, IM2COL, NARROW, EPI>), grid, block, 0, st, g);
+    else if (vb4) hipLaunchKernelGGL((gemm_f32_kernel<AKC, BKC, 1, 4, IM2COL, NARROW, EPI>), grid, block, 0, st, g);
+    else hipLaunchKernelGGL((gemm_f32_kernel<AKC, BKC, 1, 1, IM2COL, NARROW, EPI>), grid, block, 0, st, g);
     WFD_CHECK_LAUNCH();
     return WFD_OK;
+}
+
+template <bool AKC, bool BKC, bool IM2COL>
+int launch_gemm(const GemmArgs& g, int splits, bool va4, bool vb4, hipStream_t st) {
+    if (g.narrow) {
+        if (g.epi) return launch_gemm2<AKC, BKC, IM2COL, true, true>(g, splits, va4, vb4, st);
+        return launch_gemm2<AKC, BKC, IM2COL, true, false>(g, splits, va4, vb4, st);
+    }
+    if (g.epi) return launch_gemm2<AKC, BKC, IM2COL, false, true>(g, splits, va4, vb4, st);
+    return launch_gemm2<AKC, BKC, IM2COL, false, false>(g, splits, va4, vb4, st);
 }
 
 inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
@@ -225,7 +289,7 @@ extern "C" {
 // Number of K splits the library would pick for an (M,N,K) product: enough workgroups to cover the 256 CUs about
 // twice, never thinner than 2 k-tiles per split.  The caller sizes the slab workspace with it.
 int wfd_gemm_pick_splits(int M, int N, int K) {
-    const int tiles = cdiv(M, BM) * cdiv(N, BN);
+    const int tiles = cdiv(M, BM) * (N <= 32 ? cdiv(N, 32) : cdiv(N, BN));
     const int ktiles = cdiv(K, BK);
     int s = 512 / (tiles > 0 ? tiles : 1);
     if (s < 1) s = 1;
@@ -243,6 +307,7 @@ int wfd_gemm_f32(int layout, const float* A, int lda, const float* B, int ldb, f
     g.A = A; g.B = B; g.P = P; g.M = M; g.N = N; g.K = K; g.lda = lda; g.ldb = ldb; g.ldp = ldp;
     g.slab_stride = slab_stride;
     g.ktiles_per_split = cdiv(cdiv(K, BK), splits);
+    g.narrow = N <= 32;
     hipStream_t st = (hipStream_t)stream;
     const bool va4 = aligned16(A) && (lda % 4 == 0), vb4 = aligned16(B) && (ldb % 4 == 0);
     switch (layout) {
@@ -266,8 +331,46 @@ int wfd_conv8_gemm_f32(const float* X, int Bn, int L, int Cin, int pad, const fl
     g.slab_stride = slab_stride;
     g.ktiles_per_split = cdiv(cdiv(g.K, BK), splits);
     g.convL = L; g.convCin = Cin; g.convPad = pad;
+    g.narrow = Cout <= 32;
     if (splits > 1 && slab_stride < (long)g.M * ldp) return WFD_ERR_ARG;
     return launch_gemm<true, true, true>(g, splits, true, true, (hipStream_t)stream);
+}
+
+// Same contraction with the consumer's element-wise math fused into the store (one split, no slab round trip):
+//   epi 1: out = act(acc * scale[n] + shift[n])         (wfd_ep_affine_act)
+//   epi 2: out = acc * f(D[m][n]) * scale[n]            (wfd_ep_mul without the second copy)
+int wfd_gemm_f32_fused(int layout, const float* A, int lda, const float* B, int ldb, float* out, int ldo, int M, int N,
+                       int K, int epi, const float* scale, const float* shift, int act, const float* D, int ldd,
+                       int dmode, void* stream) {
+    if (!A || !B || !out || M <= 0 || N <= 0 || K <= 0 || ldo < N || epi < 1 || epi > 2) return WFD_ERR_ARG;
+    if (epi == 2 && dmode && !D) return WFD_ERR_ARG;
+    GemmArgs g{};
+    g.A = A; g.B = B; g.P = out; g.M = M; g.N = N; g.K = K; g.lda = lda; g.ldb = ldb; g.ldp = ldo;
+    g.ktiles_per_split = cdiv(K, BK);
+    g.narrow = N <= 32;
+    g.epi = epi; g.act = act; g.dmode = dmode; g.ldd = ldd; g.scale = scale; g.shift = shift; g.D = D;
+    hipStream_t st = (hipStream_t)stream;
+    const bool va4 = aligned16(A) && (lda % 4 == 0), vb4 = aligned16(B) && (ldb % 4 == 0);
+    switch (layout) {
+        case 0: if (lda < K || ldb < K) return WFD_ERR_ARG; return launch_gemm<true, true, false>(g, 1, va4, vb4, st);
+        case 1: if (lda < K || ldb < N) return WFD_ERR_ARG; return launch_gemm<true, false, false>(g, 1, va4, vb4, st);
+        case 2: if (lda < M || ldb < N) return WFD_ERR_ARG; return launch_gemm<false, false, false>(g, 1, va4, vb4, st);
+        default: return WFD_ERR_ARG;
+    }
+}
+
+int wfd_conv8_gemm_f32_fused(const float* X, int Bn, int L, int Cin, int pad, const float* Wp, int Cout, float* out,
+                             int ldo, int epi, const float* scale, const float* shift, int act, const float* D, int ldd,
+                             int dmode, void* stream) {
+    if (!X || !Wp || !out || Bn <= 0 || L <= 0 || Cin <= 0 || (Cin & 3) || Cout <= 0 || ldo < Cout) return WFD_ERR_ARG;
+    if (!aligned16(X) || !aligned16(Wp) || epi < 1 || epi > 2 || (epi == 2 && dmode && !D)) return WFD_ERR_ARG;
+    GemmArgs g{};
+    g.A = X; g.B = Wp; g.P = out; g.M = Bn * L; g.N = Cout; g.K = 8 * Cin; g.lda = Cin; g.ldb = 8 * Cin; g.ldp = ldo;
+    g.ktiles_per_split = cdiv(g.K, BK);
+    g.convL = L; g.convCin = Cin; g.convPad = pad;
+    g.narrow = Cout <= 32;
+    g.epi = epi; g.act = act; g.dmode = dmode; g.ldd = ldd; g.scale = scale; g.shift = shift; g.D = D;
+    return launch_gemm<true, true, true>(g, 1, true, true, (hipStream_t)stream);
 }
 
 }  // extern "C"

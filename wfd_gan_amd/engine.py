@@ -133,19 +133,15 @@ def observer_forward(p: Plan, df: "ObserverDF", X, ldx: int, xoff: int, B: int, 
     cur, lvl, pi = Y[0], 0, 0
     for k in range(1, 7):
         c = cv[k]
-        s = p.conv8(cur, B, Ls[lvl], c["cin"], 3, c["w"], c["cout"])
-        p.affine_act(s, c["scale"], c["shift"], c["act"], Y[k], c["cout"])
+        p.conv8_affine(cur, B, Ls[lvl], c["cin"], 3, c["w"], c["cout"], c["scale"], c["shift"], c["act"], Y[k])
         cur = Y[k]
         if c["pool"]:
             p.add(L.df_pool8_fwd, ptr(cur), B, Ls[lvl], c["cout"], ptr(PO[pi]))
             cur, lvl, pi = PO[pi], lvl + 1, pi + 1
     kin = 256 * Ls[4]
-    s = p.gemm(NT, PO[3], kin, df.fc1_w, kin, B, 512, kin)
-    p.affine_act(s, df.fc1_scale, df.fc1_shift, ACT_RELU, F1, 512)
-    s = p.gemm(NT, F1, 512, df.fc2_w, 512, B, 512, 512)
-    p.affine_act(s, df.fc2_scale, df.fc2_shift, ACT_RELU, F2, 512)
-    s = p.gemm(NT, F2, 512, df.fc_w, 512, B, df.C, 512)
-    p.affine_act(s, None, df.fc_b, ACT_NONE, LOG, ldc)
+    p.gemm_affine(NT, PO[3], kin, df.fc1_w, kin, B, 512, kin, df.fc1_scale, df.fc1_shift, ACT_RELU, F1, 512)
+    p.gemm_affine(NT, F1, 512, df.fc2_w, 512, B, 512, 512, df.fc2_scale, df.fc2_shift, ACT_RELU, F2, 512)
+    p.gemm_affine(NT, F2, 512, df.fc_w, 512, B, df.C, 512, None, df.fc_b, ACT_NONE, LOG, ldc)
 
 
 class TrainEngine:
@@ -254,7 +250,8 @@ class TrainEngine:
         b["LOG"], b["DLOG"], b["CE"] = z(B, self.ldc), z(B, self.ldc), z(B)
         self.ldl = rup(S - 1, 4)
         b["DDF"] = z(B, self.ldl)
-        b["ws"] = torch.empty(workspace_mb * (1 << 18), **f32)
+        # slab workspace: at least the largest raw product of a step (first DF conv block: B*L x 32, split-K x2)
+        b["ws"] = torch.empty(max(workspace_mb * (1 << 18), B * S * 64), **f32)
         b["ws2"] = torch.empty(64 * (1 << 18), **f32)        # slab workspace of the side lane
         self.overlap = overlap
 
@@ -489,14 +486,14 @@ class TrainEngine:
                       c["act"], ptr(DC[k]))
                 pi -= 1
             # DC[k] = gradient at conv k's raw output.  Push it through conv k to the activation feeding it.
-            s = p.conv8(DC[k], B, Ls[lvl], c["cout"], 4, c["wT"], c["cin"])
             prev = cv[k - 1]
             if prev["pool"]:
-                p.mul(s, None, 0, DM_NONE, None, None, DPO[pi], None, c["cin"])
+                p.conv8_mul(DC[k], B, Ls[lvl], c["cout"], 4, c["wT"], c["cin"], None, 0, DM_NONE, None, DPO[pi])
                 lvl -= 1
             else:
                 dm = DM_ELU if prev["act"] == ACT_ELU else DM_RELU
-                p.mul(s, Y[k - 1], prev["cout"], dm, prev["scale"], None, DC[k - 1], None, prev["cout"])
+                p.conv8_mul(DC[k], B, Ls[lvl], c["cout"], 4, c["wT"], c["cin"], Y[k - 1], prev["cout"], dm,
+                            prev["scale"], DC[k - 1])
             k -= 1
         p.add(self.L.df_conv1_bwd, ptr(DC[0]), B, Ls[0], 32, ptr(cv[0]["w_raw"]), ptr(b["DDF"]), self.ldl)
 

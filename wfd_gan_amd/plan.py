@@ -166,6 +166,35 @@ class Plan:
         self.add(self.L.conv8_gemm_f32, ptr(X), Bn, L, Cin, pad, ptr(Wp), Cout, ptr(self.ws), ldp, ss, ns)
         return Slabs(ptr(self.ws), ns, ss, ldp, M, Cout)
 
+    # -- contraction + element-wise consumer: fused into one launch when a single split fills the chip ------------
+    def gemm_affine(self, layout, A, lda, B, ldb, M, N, K, scale, shift, act, out, ldo):
+        if self.L.gemm_pick_splits(M, N, K) == 1:
+            self.add(self.L.gemm_f32_fused, layout, ptr(A), lda, ptr(B), ldb, ptr(out), ldo, M, N, K, 1, ptr(scale),
+                     ptr(shift), act, 0, 0, 0)
+        else:
+            self.affine_act(self.gemm(layout, A, lda, B, ldb, M, N, K), scale, shift, act, out, ldo)
+
+    def gemm_mul(self, layout, A, lda, B, ldb, M, N, K, D, ldd, dmode, colscale, out, ldo):
+        if self.L.gemm_pick_splits(M, N, K) == 1:
+            self.add(self.L.gemm_f32_fused, layout, ptr(A), lda, ptr(B), ldb, ptr(out), ldo, M, N, K, 2, ptr(colscale),
+                     0, 0, ptr(D), ldd, dmode)
+        else:
+            self.mul(self.gemm(layout, A, lda, B, ldb, M, N, K), D, ldd, dmode, colscale, None, out, None, ldo)
+
+    def conv8_affine(self, X, Bn, L, Cin, pad, Wp, Cout, scale, shift, act, out):
+        if self.L.gemm_pick_splits(Bn * L, Cout, 8 * Cin) == 1:
+            self.add(self.L.conv8_gemm_f32_fused, ptr(X), Bn, L, Cin, pad, ptr(Wp), Cout, ptr(out), Cout, 1, ptr(scale),
+                     ptr(shift), act, 0, 0, 0)
+        else:
+            self.affine_act(self.conv8(X, Bn, L, Cin, pad, Wp, Cout), scale, shift, act, out, Cout)
+
+    def conv8_mul(self, X, Bn, L, Cin, pad, Wp, Cout, D, ldd, dmode, colscale, out):
+        if self.L.gemm_pick_splits(Bn * L, Cout, 8 * Cin) == 1:
+            self.add(self.L.conv8_gemm_f32_fused, ptr(X), Bn, L, Cin, pad, ptr(Wp), Cout, ptr(out), Cout, 2,
+                     ptr(colscale), 0, 0, ptr(D), ldd, dmode)
+        else:
+            self.mul(self.conv8(X, Bn, L, Cin, pad, Wp, Cout), D, ldd, dmode, colscale, None, out, None, Cout)
+
     # -- epilogues ----------------------------------------------------------------------------------------
     def affine_act(self, s: Slabs, scale, shift, act: int, out, ldo: int):
         self.add(self.L.ep_affine_act, s.ptr, s.ns, s.ss, s.ldp, s.M, s.N, ptr(scale), ptr(shift), act, ptr(out), ldo)

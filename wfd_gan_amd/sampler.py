@@ -69,12 +69,11 @@ class BulkSampler:
         pr.add(self.L.iter_advance, self.state.data_ptr(), (M * Z + 3) // 4, 0)
         p = Plan(self.ws)
         p.add(self.L.onehot_rows, ptr(self.labels), M, C, ptr(self.zin), self.ldz, Z)
-        s = p.gemm(NT, self.zin, self.ldz, self.w[0], Z + C, M, 512, Z + C)
-        p.affine_act(s, None, self.b0, ACT_RELU, self.h1, 512)
-        s = p.gemm(NT, self.h1, 512, self.w[1], 512, M, 1024, 512)
-        p.affine_act(s, self.aff[0][0], self.aff[0][1], ACT_RELU, self.h2, 1024)
-        s = p.gemm(NT, self.h2, 1024, self.w[2], 1024, M, 2048, 1024)
-        p.affine_act(s, self.aff[1][0], self.aff[1][1], ACT_RELU, self.h3, 2048)
+        p.gemm_affine(NT, self.zin, self.ldz, self.w[0], Z + C, M, 512, Z + C, None, self.b0, ACT_RELU, self.h1, 512)
+        p.gemm_affine(NT, self.h1, 512, self.w[1], 512, M, 1024, 512, self.aff[0][0], self.aff[0][1], ACT_RELU,
+                      self.h2, 1024)
+        p.gemm_affine(NT, self.h2, 1024, self.w[2], 1024, M, 2048, 1024, self.aff[1][0], self.aff[1][1], ACT_RELU,
+                      self.h3, 2048)
         s = p.gemm(NT, self.h3, 2048, self.w[3], 2048, M, S, 2048)
         p.add(self.L.ep_sigmoid_lenmask, s.ptr, s.ns, s.ss, s.ldp, M, S, ptr(self.b8), self.srange, self.smin,
               ptr(self.y), self.ldy, ptr(self.idx), ptr(self.err))
