@@ -76,7 +76,8 @@ def gemm_roofline(eng, n_iters=6):
     the same fast-mode plans; returns achieved TFLOP/s = sum(flops) / sum(duration) and the per-launch averages."""
     from wfd_gan_amd.plan import HOST
     L = eng.L
-    gemm_fns = {L.gemm_f32: "gemm", L.conv8_gemm_f32: "conv"}
+    gemm_fns = {L.gemm_f32: "gemm", L.conv8_gemm_f32: "conv", L.gemm_f32_fused: "gemm_fused",
+                L.conv8_gemm_f32_fused: "conv"}
     from wfd_gan_amd.plan import FORK, JOIN
     stream = torch.cuda.current_stream().cuda_stream
     recs = []
@@ -95,6 +96,8 @@ def gemm_roofline(eng, n_iters=6):
                     continue
                 if kind == "gemm":
                     M, N, K = a[8], a[9], a[10]
+                elif kind == "gemm_fused":
+                    M, N, K = a[7], a[8], a[9]
                 else:
                     M, N, K = a[1] * a[2], a[6], 8 * a[3]
                 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -207,8 +210,21 @@ def main():
             bs.run_chunk(labels)
         barrier()
         sdt = parallel.max_over_ranks(time.perf_counter() - t1, device)
-        samp = dict(value=world * nchunks * chunk / sdt, unit="traces/s", chunk=chunk,
+        samp = dict(value=world * nchunks * chunk / sdt, unit="traces/s", chunk=chunk, operands="f32",
                     note="int32 burst vectors left on device; eval generator + inverse-scale/rint/trim epilogue")
+        # same sampler with bf16-operand MFMA (not the parity path; tolerance in tests/test_gpu_bf16.py)
+        bs16 = BulkSampler(eng.generator_state(), args.seq_len, args.classes, args.latent_dim, dmin, dmax, chunk=chunk,
+                           device=device, seed=99 + rank, operands="bf16")
+        bs16.capture()
+        for _ in range(2):
+            bs16.run_chunk(labels)
+        barrier()
+        t1 = time.perf_counter()
+        for _ in range(nchunks):
+            bs16.run_chunk(labels)
+        barrier()
+        sdt16 = parallel.max_over_ranks(time.perf_counter() - t1, device)
+        samp["bf16_operands_traces_per_s"] = world * nchunks * chunk / sdt16
 
     if rank == 0:
         out = {

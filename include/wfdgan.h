@@ -51,6 +51,17 @@ int wfd_conv8_gemm_f32_fused(const float* X, int Bn, int L, int Cin, int pad, co
                              int ldo, int epi, const float* scale, const float* shift, int act, const float* D, int ldd,
                              int dmode, void* stream);
 
+/* bf16-operand MFMA (fp32 accumulate) NT product for the large-batch forward path (bulk sampling, BASELINE config
+ * 4/5): A (M,K) and B (N,K) bf16 row-major, K and both leading dimensions multiples of 8, 16-byte aligned.
+ * O != NULL: O = bf16(act(acc*scale[n]+shift[n])) (act 0 none, 1 ReLU, 3 sigmoid); else raw fp32 into P.
+ * nn.Linear (+ folded eval BatchNorm + ReLU) of src/model.py:28-32 at bf16 operand precision -- NOT the parity
+ * path (fp32 kernels above); tolerance stated in tests/test_gpu_bf16.py. */
+int wfd_gemm_bf16_nt(const void* A, int lda, const void* B, int ldb, int M, int N, int K, float* P, int ldp, void* O,
+                     int ldo, const float* scale, const float* shift, int act, void* stream);
+
+/* fp32 -> bf16 (round-to-nearest-even) with zero padding of columns [N, Npad) */
+int wfd_f32_to_bf16(const float* in, int ldi, void* out, int ldo, int M, int N, int Npad, void* stream);
+
 /* ---- MLP epilogues ------------------------------------------------------------------------------------ */
 
 /* out = act(sumP * scale[n] + shift[n]); act 0 none, 1 ReLU, 2 ELU, 3 sigmoid; scale/shift may be NULL.

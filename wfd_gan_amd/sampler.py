@@ -26,7 +26,14 @@ def minmax_params(data_min: np.ndarray, data_max: np.ndarray) -> Tuple[np.ndarra
 
 class BulkSampler:
     def __init__(self, G_state: Dict[str, torch.Tensor], seq_len: int, class_dim: int, latent_dim: int,
-                 data_min: np.ndarray, data_max: np.ndarray, chunk: int = 8192, device="cuda:0", seed: int = 0):
+                 data_min: np.ndarray, data_max: np.ndarray, chunk: int = 8192, device="cuda:0", seed: int = 0,
+                 operands: str = "f32"):
+        """operands = "f32": exact-fp32 MFMA (the parity path: integers match the reference except at rounding
+        boundaries); "bf16": bf16-operand MFMA for the four Linear layers (weights and hidden activations rounded to
+        bf16, fp32 accumulate and epilogues) -- several times faster, values within ~1e-2 of the fp32 path."""
+        if operands not in ("f32", "bf16"):
+            raise ValueError("operands must be 'f32' or 'bf16'")
+        self.operands = operands
         if not torch.cuda.is_available():
             raise RuntimeError("wfd_gan_amd.BulkSampler needs a HIP device: there is no CPU path")
         self.L = lib()
@@ -59,6 +66,13 @@ class BulkSampler:
         self.err = torch.zeros(1, dtype=torch.int32, device=dev)
         self.state = torch.zeros(2, dtype=torch.int64, device=dev)
         self.ws = torch.empty(max(M, 64) * 2048 * 2, dtype=torch.float32, device=dev)
+        if operands == "bf16":
+            bf = lambda *s: torch.zeros(*s, dtype=torch.bfloat16, device=dev)
+            self.k0 = rup(Z + C, 8)
+            w0 = torch.zeros(512, self.k0, dtype=torch.float32, device=dev)
+            w0[:, : Z + C] = self.w[0]
+            self.w16 = [w0.to(torch.bfloat16).contiguous()] + [w.to(torch.bfloat16).contiguous() for w in self.w[1:]]
+            self.zin16, self.h1_16, self.h2_16, self.h3_16 = bf(M, self.k0), bf(M, 512), bf(M, 1024), bf(M, 2048)
         self.plan_rng, self.plan = self._build()
         self.graph = None
 
@@ -69,6 +83,23 @@ class BulkSampler:
         pr.add(self.L.iter_advance, self.state.data_ptr(), (M * Z + 3) // 4, 0)
         p = Plan(self.ws)
         p.add(self.L.onehot_rows, ptr(self.labels), M, C, ptr(self.zin), self.ldz, Z)
+        if self.operands == "bf16":
+            L = self.L
+            p.add(L.f32_to_bf16, ptr(self.zin), self.ldz, ptr(self.zin16), self.k0, M, Z + C, self.k0)
+            p.add(L.gemm_bf16_nt, ptr(self.zin16), self.k0, ptr(self.w16[0]), self.k0, M, 512, self.k0, 0, 0,
+                  ptr(self.h1_16), 512, 0, ptr(self.b0), ACT_RELU)
+            p.add(L.gemm_bf16_nt, ptr(self.h1_16), 512, ptr(self.w16[1]), 512, M, 1024, 512, 0, 0, ptr(self.h2_16), 1024,
+                  ptr(self.aff[0][0]), ptr(self.aff[0][1]), ACT_RELU)
+            p.add(L.gemm_bf16_nt, ptr(self.h2_16), 1024, ptr(self.w16[2]), 1024, M, 2048, 1024, 0, 0, ptr(self.h3_16),
+                  2048, ptr(self.aff[1][0]), ptr(self.aff[1][1]), ACT_RELU)
+            ldp = rup(S, 4)
+            p.add(L.gemm_bf16_nt, ptr(self.h3_16), 2048, ptr(self.w16[3]), 2048, M, S, 2048, ptr(self.ws), ldp, 0, 0, 0, 0,
+                  0)
+            p.add(L.ep_sigmoid_lenmask, ptr(self.ws), 1, 0, ldp, M, S, ptr(self.b8), self.srange, self.smin, ptr(self.y),
+                  self.ldy, ptr(self.idx), ptr(self.err))
+            p.add(L.sample_post, ptr(self.y), self.ldy, M, S, ptr(self.min_d), ptr(self.scale_d), ptr(self.out), S,
+                  ptr(self.lens))
+            return pr, p
         p.gemm_affine(NT, self.zin, self.ldz, self.w[0], Z + C, M, 512, Z + C, None, self.b0, ACT_RELU, self.h1, 512)
         p.gemm_affine(NT, self.h1, 512, self.w[1], 512, M, 1024, 512, self.aff[0][0], self.aff[0][1], ACT_RELU,
                       self.h2, 1024)
