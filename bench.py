@@ -50,7 +50,12 @@ def build_engine(args, rank, world, device):
     from wfd_gan_amd.engine import TrainEngine
     from wfd_gan_amd.model import DF, Discriminator, Generator
     S, C, Z, B = args.seq_len, args.classes, args.latent_dim, args.batch
-    X, y = synth_dataset_device(C, args.inst, S - 1, 50, 75, 179, 1000 + rank, device)
+    strong = args.dp == "strong" and world > 1
+    if strong:                                # the global batch of --batch rows split over the ranks, SyncBN
+        assert B % world == 0, "--dp strong needs --batch divisible by the number of ranks"
+        B //= world
+    # weak: every rank trains on its own data; strong: all ranks hold the same data and permutation
+    X, y = synth_dataset_device(C, args.inst, S - 1, 50, 75, 179, 1000 + (0 if strong else rank), device)
     dmin, dmax = X.min(0).values, X.max(0).values
     rngv = torch.where(dmax > dmin, dmax - dmin, torch.ones_like(dmax))
     Xs = (X - dmin) / rngv
@@ -61,8 +66,8 @@ def build_engine(args, rank, world, device):
     pg = None
     eng = TrainEngine(S, C, Z, B, float(dmin[0]), float(dmax[0]), G.state_dict(), D.state_dict(), F.state_dict(),
                       lr=2e-4, alpha=0.02, n_critic=3, penalty=args.penalty, device=device, seed=1234 + rank,
-                      process_group=pg, world_size=world, overlap=bool(args.overlap))
-    eng.attach_dataset(Xs, y, shuffle_seed=rank)
+                      process_group=pg, world_size=world, overlap=bool(args.overlap), rank=rank, sync_bn=strong)
+    eng.attach_dataset(Xs, y, shuffle_seed=0 if strong else rank)
     return eng, (dmin.double().cpu().numpy(), dmax.double().cpu().numpy())
 
 
@@ -156,6 +161,9 @@ def main():
     ap.add_argument("--penalty", default="div", choices=["div", "gp"])
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--overlap", type=int, default=0, help="1: independent branches of a step on a side stream")
+    ap.add_argument("--dp", default="weak", choices=["weak", "strong"],
+                    help="N > 1: weak = --batch rows per GPU (DDP semantics, the driver's scaling runs); strong = --batch "
+                         "rows split over the GPUs with SyncBN (result-equal to one GPU)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-sampling", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=20.0)
@@ -230,12 +238,13 @@ def main():
         out = {
             "metric": "WGAN train iterations/s (100-class, L=1400, B=64/GPU, fp32; D-step every iter, G-step every 3rd)",
             "value": its * 1.0, "unit": "iterations/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "strong" if (args.dp == "strong" and world > 1) else "weak",
+            "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
             "config": {"workload": "configs[1]: 100 sites x 1000 inst synthetic bursts, L=1400 (S=1401), batch "
                                    f"{args.batch}/GPU, latent {args.latent_dim}, n_critic 3, alpha 0.02, RMSprop 2e-4, "
                                    f"penalty={args.penalty} ({'W-div k=2 p=6, what the reference runs' if args.penalty == 'div' else 'WGAN-GP interpolate'})",
-                       "global_batch": args.batch * world, "samples_per_s": its * args.batch * world,
+                       "global_batch": eng.B * world, "samples_per_s": its * eng.B * world,
                        "parallelism": f"dp{world}", "graphs": not args.no_graph},
             "roofline": {"bound": "mfma", "achieved": roof["tflops"], "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
                          "frac": roof["tflops"] / PEAK_F32_MFMA_TFLOPS, "traffic": traffic,

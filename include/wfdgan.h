@@ -204,10 +204,11 @@ int wfd_iter_advance(unsigned long long* state, unsigned long long inc0, unsigne
 
 /* one training batch: rows idx[] of the resident dataset + one-hot labels into the real / fake / generator-input
  * buffers (DataLoader + np.eye(class_dim)[c], src/mlp_df_wgan_train.py:182-186); row b reads
- * idx[(state[1] + b) mod n_idx], clamped to [0, n_rows) */
+ * idx[(state[1] + row_offset + b) mod n_idx], clamped to [0, n_rows); row_offset = rank * B picks this rank's rows
+ * of a global batch in data-parallel runs */
 int wfd_gather_batch(const float* X, int ldX, const int* y, const long long* idx, const unsigned long long* state,
-                     long n_idx, long n_rows, int B, int S, int C, float* real, float* fake, int ldd, float* zin,
-                     int ldz, int Z, int* labels_out, void* stream);
+                     long n_idx, long n_rows, long row_offset, int B, int S, int C, float* real, float* fake, int ldd,
+                     float* zin, int ldz, int Z, int* labels_out, void* stream);
 
 int wfd_onehot_rows(const int* labels, int M, int C, float* out, int ld, int col0, void* stream);
 

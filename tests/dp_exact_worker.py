@@ -1,0 +1,101 @@
+"""Worker of tests/test_gpu_dp_exact.py: one rank of the exact (global-batch, SyncBN) data-parallel mode.  The ranks
+share cuda:0 and talk over gloo (device tensors staged through the host by wfd_gan_amd.parallel.Comm), so that the
+strong-scaling arithmetic can be checked on a one-GPU box.  Each rank feeds its slice of the reference fixture's
+batch; rank 0 compares the result with the fixture (= the reference's single-process update on the whole batch)."""
+import os
+
+import numpy as np
+import torch
+
+RTOL = 1e-3
+
+
+def _close(a, b, rtol=RTOL, atol=0.0):
+    return abs(float(a) - float(b)) <= rtol * abs(float(b)) + atol
+
+
+def worker(rank, world, port, name, q):
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK="0", MASTER_ADDR="127.0.0.1",
+                      MASTER_PORT=str(port))
+    try:
+        q.put((rank, _run(rank, world, name)))
+    except Exception as e:  # noqa: BLE001 - report instead of hanging the parent on q.get
+        import traceback
+        q.put((rank, [f"rank {rank} raised: {e!r}\n{traceback.format_exc()}"]))
+
+
+def _run(rank, world, name):
+    import torch.distributed as dist
+    from tests.util import load_iter_fixture, rebuild_state, rel_err, unpack_masks
+    from wfd_gan_amd import parallel
+    from wfd_gan_amd.engine import TrainEngine
+    parallel.init_from_env(backend="gloo")
+    torch.cuda.set_device(0)
+    fx, meta = load_iter_fixture(name)
+    st = rebuild_state(meta, fx)
+    Bg = meta["batch"]
+    B = Bg // world
+    a, b = rank * B, (rank + 1) * B
+    eng = TrainEngine(meta["seq_len"], meta["class_dim"], meta["latent_dim"], B, meta["scaler_min"], meta["scaler_max"],
+                      {k: v.detach() for k, v in st.G.items()}, {k: v.detach() for k, v in st.D.items()}, st.DF,
+                      lr=meta["lr"], alpha=meta["alpha"], n_critic=meta["n_critic"], world_size=world, rank=rank,
+                      sync_bn=True)
+    assert eng.Bg == Bg and eng.gscale == 1.0
+    bad = []
+    for it in range(meta["n_iter"]):
+        p = f"it{it}_"
+        do_g = it % meta["n_critic"] == 0
+        mr, mf, mg = (unpack_masks(fx, p + k, Bg) for k in ("mreal", "mfake", "mg"))
+        eng.set_batch(torch.from_numpy(fx[p + "traces"][a:b]), torch.from_numpy(fx[p + "labels"][a:b]),
+                      torch.from_numpy(fx[p + "z"][a:b]))
+        eng.set_masks([torch.cat([x[a:b], y[a:b]]) for x, y in zip(mr, mf)], None if mg is None else [m[a:b] for m in mg])
+        eng.d_step()
+        torch.cuda.synchronize()
+        s = eng.d_stats()
+        d_loss, pen, w_dist, mrv, mfv = fx[p + "scalars"]
+        chk = [("penalty", _close(s["penalty"], pen)), ("mean_rv", _close(s["mean_rv"], mrv, atol=2e-5)),
+               ("mean_fv", _close(s["mean_fv"], mfv, atol=2e-5)), ("d_loss", _close(s["d_loss"], d_loss, atol=4e-5)),
+               ("w_dist", _close(s["w_dist"], w_dist, atol=4e-5)),
+               ("idx", np.array_equal(eng.buf["idx"].cpu().numpy(), fx[p + "idx_d"][a:b])),
+               ("n_r", rel_err(eng.buf["PEN"][:B].cpu().numpy(), fx[p + "n_r"][a:b]) < RTOL),
+               ("n_f", rel_err(eng.buf["PEN"][B:2 * B].cpu().numpy(), fx[p + "n_f"][a:b]) < RTOL)]
+        if do_g:
+            eng.g_step()
+            torch.cuda.synchronize()
+            g = eng.g_stats()
+            g_loss, f_loss, comb, nsel = fx[p + "g_scalars"]
+            chk += [("g_loss", _close(g["g_loss"], g_loss, atol=2e-5)), ("n_sel", g["n_sel"] == int(nsel)),
+                    ("f_loss", _close(g["f_loss"], f_loss, atol=2e-5)),
+                    ("combined", _close(g["g_combined"], comb, atol=4e-5))]
+        dnorm = np.array([float(eng.Dp.p[n].double().norm()) for n, _ in eng.Dp.specs])
+        gnorm = np.array([float(eng.Gp.p[n].double().norm()) for n, _ in eng.Gp.specs])
+        bn = torch.cat([eng.Gbuf[f"model.{i}.{s}"] for i in (3, 6) for s in ("running_mean", "running_var")])
+        chk += [("D param norms", rel_err(dnorm, fx[p + "d_param_norms"]) < RTOL),
+                ("G param norms", rel_err(gnorm, fx[p + "g_param_norms"]) < RTOL),
+                ("BN running stats", rel_err(bn.cpu().numpy(), fx[p + "g_bn_stats"]) < RTOL)]
+        bad += [f"rank {rank} it{it} {k}" for k, ok in chk if not ok]
+    # replicas must hold identical parameters after the run
+    flat = torch.cat([eng.Dp.flat, eng.Gp.flat]).cpu()
+    both = [torch.empty_like(flat) for _ in range(world)]
+    dist.all_gather(both, flat)
+    if not all(torch.equal(both[0], t) for t in both[1:]):
+        bad.append(f"rank {rank}: replicas diverged (max |d| = {float((both[0] - both[-1]).abs().max()):.3e})")
+    dist.barrier()
+    dist.destroy_process_group()
+    return bad
+
+
+def trainer_worker(rank, world, port, argv, q):
+    """One torchrun-style rank of the trainer CLI (ranks share cuda:0, gloo)."""
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK="0", MASTER_ADDR="127.0.0.1",
+                      MASTER_PORT=str(port), WFD_DIST_BACKEND="gloo")
+    try:
+        import torch.distributed as dist
+        from wfd_gan_amd import mlp_df_wgan_train
+        out = mlp_df_wgan_train.main(argv)
+        dist.barrier()
+        dist.destroy_process_group()
+        q.put((rank, out, None))
+    except BaseException as e:  # noqa: BLE001
+        import traceback
+        q.put((rank, None, f"rank {rank} raised: {e!r}\n{traceback.format_exc()}"))

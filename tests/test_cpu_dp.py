@@ -54,6 +54,16 @@ def _worker(rank, world, port, q):
     gs.start(flat2[cut:])
     gs.finish()
     ok = ok and torch.allclose(flat2 / world, want, rtol=0, atol=1e-7) and not gs.pending
+    # SyncBN combine: (mean, M2) of two row shards -> the pair over all rows
+    xg = torch.Generator().manual_seed(5)
+    xs = torch.randn(12, 7, generator=xg, dtype=torch.float64) * 3 + 1
+    mine = xs[6 * rank: 6 * (rank + 1)]
+    mean, m2 = mine.mean(0), ((mine - mine.mean(0)) ** 2).sum(0)
+    comm = parallel.Comm()
+    comm.combine_bn_stats_(mean, m2, 6)
+    ok = ok and torch.allclose(mean, xs.mean(0), atol=1e-12) and torch.allclose(m2, ((xs - xs.mean(0)) ** 2).sum(0), atol=1e-10)
+    ok = ok and comm.all_gather(torch.tensor([float(rank)])).flatten().tolist() == [0.0, 1.0]
+    ok = ok and comm.all_reduce_sum_(torch.tensor([1.0 + rank])).item() == 3.0
     tmax = parallel.max_over_ranks(float(rank + 1), "cpu")
     tsum = parallel.sum_over_ranks(1.0, "cpu")
     t = torch.full((3,), float(rank))

@@ -1,0 +1,119 @@
+"""GPU: exact data-parallel mode (SURVEY.md 8e "strong": the global batch split over ranks, SyncBN, global selected-row
+count, summed gradients) against the reference fixtures.  Two ranks share cuda:0 and exchange over gloo; each feeds
+half of the fixture's batch, and the update must equal the reference's single-process update on the whole batch to
+the fp32 tolerance (1e-3).  Also the one-rank degenerate case of the staged path in-process."""
+import socket
+
+import pytest
+import torch
+import torch.multiprocessing as mp
+
+from tests.dp_exact_worker import trainer_worker, worker
+
+pytestmark = pytest.mark.gpu
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+@pytest.mark.parametrize("name,world", [("tiny", 2), ("cfg2", 2), ("cfg2", 4)])
+def test_exact_dp_equals_reference_update(name, world):
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=worker, args=(r, world, port, name, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    out = [q.get(timeout=280) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+    bad = [m for _, msgs in out for m in msgs]
+    assert not bad, "\n".join(bad)
+    assert all(p.exitcode == 0 for p in procs)
+
+
+def test_exact_mode_single_rank_is_plain_step():
+    """sync_bn=True at world 1 runs the split BN kernels and the host stages but must reproduce the fused path."""
+    from tests.test_gpu_step import make_engine
+    from tests.util import load_iter_fixture, rebuild_state, unpack_masks
+    from wfd_gan_amd.engine import TrainEngine
+    fx, meta = load_iter_fixture("cfg1")
+    B = meta["batch"]
+    engs = []
+    for exact in (False, True):
+        st = rebuild_state(meta, fx)
+        if not exact:
+            eng = make_engine(st, meta, B)
+        else:
+            eng = TrainEngine(meta["seq_len"], meta["class_dim"], meta["latent_dim"], B, meta["scaler_min"],
+                              meta["scaler_max"], {k: v.detach() for k, v in st.G.items()},
+                              {k: v.detach() for k, v in st.D.items()}, st.DF, lr=meta["lr"], alpha=meta["alpha"],
+                              n_critic=meta["n_critic"], sync_bn=True, force_sync=True)
+        for it in range(2):
+            p = f"it{it}_"
+            mr, mf, mg = (unpack_masks(fx, p + k, B) for k in ("mreal", "mfake", "mg"))
+            eng.set_batch(torch.from_numpy(fx[p + "traces"]), torch.from_numpy(fx[p + "labels"]),
+                          torch.from_numpy(fx[p + "z"]))
+            eng.set_masks([torch.cat([a, b]) for a, b in zip(mr, mf)], mg)
+            eng.d_step()
+            if it == 0:
+                eng.g_step()
+        torch.cuda.synchronize()
+        engs.append(eng)
+    a, b = engs
+    for x, y in ((a.Dp.flat, b.Dp.flat), (a.Gp.flat, b.Gp.flat)):
+        assert float((x - y).abs().max()) <= 1e-6 * float(x.abs().max())
+
+
+@pytest.mark.parametrize("mode", ["strong", "weak"])
+def test_trainer_cli_two_ranks(tmp_path, mode):
+    """The trainer under a 2-rank launch: rank 0 writes the reference's artefacts, the per-epoch files hold every
+    rank's generated rows, the ragged tail is split over the ranks."""
+    import glob
+    import os
+    import re
+
+    import numpy as np
+    from oracle import wfdgan_oracle as O
+    n_cls, n_inst, L = 5, 24, 40           # 120 rows
+    X, y = O.synth_dataset(n_cls, n_inst, L, 4, 13, 122, seed=0)
+    ddir = tmp_path / "ds" / "feature"
+    ddir.mkdir(parents=True)
+    npz = str(ddir / "raw_feature_synth.npz")
+    np.savez(npz, features=X, labels=y)
+    torch.manual_seed(0)
+    ck = str(tmp_path / "df.ckpt")
+    torch.save(O.make_df_state(L, n_cls), ck)
+    # strong: global batch 16 = 2 x 8 -> 7 full + tail 8 (4 per rank); weak: 2 x 16 -> 3 full + tail 24 (12 per rank)
+    argv = ["-d", npz, "--f_model", ck, "--n_epochs", "2", "--batch_size", "16", "--latent_dim", "24", "--seed", "7",
+            "--freq", "2", "--dp", mode]
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=trainer_worker, args=(r, 2, port, argv, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=280) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+    errs = [e for _, _, e in res if e]
+    assert not errs, "\n".join(errs)
+    outs = {r: o for r, o, _ in res}
+    out = outs[0]
+    assert outs[1] is None and os.path.isdir(out)
+    log = open(os.path.join(out, "log.txt")).read()
+    assert len(re.findall(r"\[Epoch +\d+/ *2\] \[D loss: ", log)) == 2
+    d = np.load(os.path.join(out, "checkpoint", "epoch_2.npz"))
+    # strong: 8 iterations, G-steps at i = 0, 3, 6 on 16 global rows; weak: 4 iterations, G-steps at i = 0 (32 rows)
+    # and i = 3 (the tail, 24 rows)
+    assert d["x"].shape == ((48, L + 1) if mode == "strong" else (56, L + 1))
+    assert np.allclose(d["x"], np.round(d["x"])) and np.isfinite(d["recon_x"]).all()
+    ls = np.load(os.path.join(out, "checkpoint", "loss.npz"))
+    assert all(len(ls[k]) == 2 and np.isfinite(ls[k]).all() for k in ("generator", "discriminator", "dist"))
+    assert len(glob.glob(os.path.join(out, "model", "generator_seqlen41_cls5_latentdim24.ckpt"))) == 1
+    assert len(glob.glob(str(tmp_path / "ds" / "training_*"))) == 1          # only rank 0 made an output directory

@@ -64,13 +64,13 @@ __global__ void rng_normal_rows_kernel(float* __restrict__ out, int ld, int M, i
 //   zin[b][Z..Z+C) = same one-hot;  labels_out[b] = y[idx[b]]
 __global__ void gather_batch_kernel(const float* __restrict__ X, int ldX, const int* __restrict__ y,
                                     const long long* __restrict__ idx, const unsigned long long* __restrict__ state,
-                                    long n_idx, long n_rows, int S, int C, float* __restrict__ real,
+                                    long n_idx, long n_rows, long row_offset, int S, int C, float* __restrict__ real,
                                     float* __restrict__ fake, int ldd, float* __restrict__ zin, int ldz, int Z,
                                     int* __restrict__ labels_out) {
     const int b = blockIdx.x;
     // the cursor wraps inside the permutation and the row index is clamped: a stale cursor can never make
     // this kernel read outside the dataset
-    long long src = idx[((state ? (long long)state[1] : 0ll) + b) % n_idx];
+    long long src = idx[((state ? (long long)state[1] : 0ll) + row_offset + b) % n_idx];
     src = src < 0 ? 0 : (src >= n_rows ? n_rows - 1 : src);
     const int lab = y[src];
     for (int j = threadIdx.x; j < S; j += blockDim.x) real[(long)b * ldd + j] = X[src * ldX + j];
@@ -237,11 +237,11 @@ int wfd_rng_normal_rows(float* out, int ld, int M, int Z, unsigned long long see
 }
 
 int wfd_gather_batch(const float* X, int ldX, const int* y, const long long* idx, const unsigned long long* state,
-                     long n_idx, long n_rows, int B, int S, int C, float* real, float* fake, int ldd, float* zin,
-                     int ldz, int Z, int* labels_out, void* stream) {
-    if (!X || !y || !idx || !real || B <= 0 || n_idx <= 0 || n_rows <= 0) return WFD_ERR_ARG;
+                     long n_idx, long n_rows, long row_offset, int B, int S, int C, float* real, float* fake, int ldd,
+                     float* zin, int ldz, int Z, int* labels_out, void* stream) {
+    if (!X || !y || !idx || !real || B <= 0 || n_idx <= 0 || n_rows <= 0 || row_offset < 0) return WFD_ERR_ARG;
     hipLaunchKernelGGL(gather_batch_kernel, dim3(B), dim3(256), 0, (hipStream_t)stream, X, ldX, y, idx, state, n_idx, n_rows,
-                       S, C, real, fake, ldd, zin, ldz, Z, labels_out);
+                       row_offset, S, C, real, fake, ldd, zin, ldz, Z, labels_out);
     WFD_CHECK_LAUNCH();
     return WFD_OK;
 }

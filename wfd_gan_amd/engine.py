@@ -152,7 +152,15 @@ class TrainEngine:
                  DF_state: Dict[str, torch.Tensor], lr: float = 2e-4, alpha: float = 0.02, n_critic: int = 3,
                  penalty: str = "div", lambda_gp: float = 10.0, device="cuda:0", global_batch: Optional[int] = None,
                  seed: int = 0, workspace_mb: int = 256, process_group=None, world_size: int = 1,
-                 share: Optional["TrainEngine"] = None, overlap: bool = False, force_sync: bool = False):
+                 share: Optional["TrainEngine"] = None, overlap: bool = False, force_sync: bool = False,
+                 sync_bn: bool = False, rank: int = 0):
+        """Data parallel, two modes:
+          * sync_bn=False (weak scaling, DDP semantics): every rank trains on its own ``batch`` rows with local
+            BatchNorm statistics and a local selected-row count; gradients are averaged over ranks.
+          * sync_bn=True (strong scaling, exact): ``batch`` is this rank's slice of a global batch of
+            ``batch * world_size`` rows; BatchNorm statistics, BatchNorm-backward sums and the selected-row count are
+            combined over ranks, every mean is over the global batch and gradients are summed -- the update equals the
+            single-GPU update on the global batch (up to fp32 summation order)."""
         if not torch.cuda.is_available():
             raise RuntimeError("wfd_gan_amd.TrainEngine needs a HIP device: there is no CPU path")
         if penalty not in ("div", "gp"):
@@ -161,7 +169,10 @@ class TrainEngine:
         self.dev = torch.device(device)
         S, C, Z, B = seq_len, class_dim, latent_dim, batch
         self.S, self.C, self.Z, self.B = S, C, Z, B
-        self.Bg = global_batch or B              # global batch: means are over all ranks' rows
+        self.exact = bool(sync_bn)
+        self.rank = int(rank)
+        # rows the batch means run over: the global batch in exact mode, this rank's batch otherwise
+        self.Bg = global_batch or (B * int(world_size) if self.exact else B)
         self.lr, self.alpha, self.n_critic = lr, alpha, n_critic
         self.penalty, self.lambda_gp = penalty, lambda_gp
         # python floats -> the fp32 constants torch would use for `tensor * scalar`
@@ -175,6 +186,8 @@ class TrainEngine:
         self.pg, self.world = process_group, int(world_size)
         self._gsync = None
         self.dp = self.world > 1 or force_sync      # force_sync: run the staged data-parallel path at world 1 (tests)
+        self.gscale = 1.0 if self.exact else 1.0 / self.world     # factor RMSprop applies to the summed gradients
+        self._comm = None
         self.nbt = {"model.3": 0, "model.6": 0}
         dev = self.dev
         f32 = dict(dtype=torch.float32, device=dev)
@@ -256,6 +269,10 @@ class TrainEngine:
         self.overlap = overlap
 
         self.iter_state = torch.zeros(2, dtype=torch.int64, device=dev)   # [philox counter, perm cursor]
+        # fast mode, data parallel: all ranks hold the same permutation; rank r takes rows [r*B, (r+1)*B) of each
+        # run of B*world indices and the cursor advances by the rows all ranks consumed
+        self.row_offset = self.rank * B if self.dp else 0
+        self.cursor_step = B * self.world
         self._fill_row_constants()
         self.plan_d = self._build_d_plan()
         self.plan_g = self._build_g_plan()
@@ -324,9 +341,20 @@ class TrainEngine:
         p.add(self.L.ep_sigmoid_lenmask, s.ptr, s.ns, s.ss, s.ldp, B, S, ptr(G["model.8.bias"]), self.range_f,
               self.smin_f, ptr(self.fake_rows), self.ldx, ptr(b["idx"]), ptr(b["err"]))
 
+    @property
+    def comm(self):
+        if self._comm is None:
+            from .parallel import Comm
+            self._comm = Comm(self.pg)
+        return self._comm
+
     def _bn_sync_hook(self, p: Plan, layer: int):
-        """data-parallel: (mean, M2) of all ranks are combined here (parallel.py); single rank: nothing."""
-        return
+        """Exact data-parallel mode: the ranks' per-feature (mean, M2) are combined into the global-batch pair between
+        the statistics kernel and the normalisation (parallel.Comm.combine_bn_stats_); otherwise nothing."""
+        if not self.exact:
+            return
+        mean, m2, B = self.buf[f"mean{layer}"], self.buf[f"m2{layer}"], self.B
+        p.host(lambda: self.comm.combine_bn_stats_(mean, m2, B))
 
     def _critic_forward(self, p: Plan, X, M: int, mk, H1, H2, H3, D1, D2, D3, V, DL3, DL3s, rowscale):
         """Discriminator.forward (src/model.py:69-72) on M rows of X, keeping d_i; ends with the head + delta_3."""
@@ -362,8 +390,8 @@ class TrainEngine:
         p = Plan(b["ws"], b["ws2"], self.overlap)
         st = self.iter_state.data_ptr()
         if fast:
-            p.add(self.L.gather_batch, ptr(self.data_X), S, ptr(self.data_y), ptr(self.perm), st, self.N, self.N, B, S,
-                  C, ptr(self.real_rows), ptr(self.fake_rows), self.ldx, ptr(b["ZIN"]), self.ldz, Z, ptr(b["labels"]))
+            p.add(self.L.gather_batch, ptr(self.data_X), S, ptr(self.data_y), ptr(self.perm), st, self.N, self.N,
+                  self.row_offset, B, S, C, ptr(self.real_rows), ptr(self.fake_rows), self.ldx, ptr(b["ZIN"]), self.ldz, Z, ptr(b["labels"]))
             p.add(self.L.rng_step_inputs, ptr(b["ZIN"]), self.ldz, B, Z, (self.seed + 7 * self.GOLD) & (2**64 - 1),
                   ptr(b["MKflat"]), b["MKflat"].numel(), 0.2, (self.seed + self.GOLD) & (2**64 - 1), st)
             if self.penalty == "gp":
@@ -417,8 +445,8 @@ class TrainEngine:
             (b["V"], 1, b["RSELF"], None, 0, None, M, 1, b["dstats"][4:5])])
         p.join()
         self._grad_sync_hook(p, "D")
-        p.add(self.L.rmsprop, ptr(D.flat), ptr(D.grad), ptr(D.sq), D.numel, self.lr, 0.99, 1e-8, 1.0 / self.world,
-              st if fast else 0, self._rng_inc() if fast else 0, B if fast else 0)
+        p.add(self.L.rmsprop, ptr(D.flat), ptr(D.grad), ptr(D.sq), D.numel, self.lr, 0.99, 1e-8, self.gscale,
+              st if fast else 0, self._rng_inc() if fast else 0, self.cursor_step if fast else 0)
         return p
 
     def _colsum_multi(self, p: Plan, name: str, segs):
@@ -498,7 +526,12 @@ class TrainEngine:
         p.add(self.L.df_conv1_bwd, ptr(DC[0]), B, Ls[0], 32, ptr(cv[0]["w_raw"]), ptr(b["DDF"]), self.ldl)
 
     def _nsel_sync_hook(self, p: Plan):
-        return
+        """Exact mode: ghead = [-sum fv / Bg, #selected] are per-rank partial sums; their all-reduce gives the global
+        g_loss and the global normaliser of the masked cross-entropy."""
+        if not self.exact:
+            return
+        ghead = self.buf["ghead"]
+        p.host(lambda: self.comm.all_reduce_sum_(ghead))
 
     def _build_g_plan(self, fast: bool = False) -> Plan:
         B, S, C, Z, b, G = self.B, self.S, self.C, self.Z, self.buf, self.Gp
@@ -545,15 +578,27 @@ class TrainEngine:
         p.gemm(TN, b["GDZ1"], 512, b["ZIN"], self.ldz, 512, Z + C, B, out=G.g["model.0.weight"], ldp=Z + C)
         p.join()
         self._grad_sync_hook(p, "G")
-        p.add(self.L.rmsprop, ptr(G.flat), ptr(G.grad), ptr(G.sq), G.numel, self.lr, 0.99, 1e-8, 1.0 / self.world,
+        p.add(self.L.rmsprop, ptr(G.flat), ptr(G.grad), ptr(G.sq), G.numel, self.lr, 0.99, 1e-8, self.gscale,
               st if fast else 0, self._rng_inc() if fast else 0, 0)
         return p
 
     def _bn_bwd(self, p: Plan, s: Slabs, i: int, lin: str, bn: str, n: int):
         b, G = self.buf, self.Gp
-        p.add(self.L.bn_bwd, s.ptr, s.ns, s.ss, s.ldp, self.B, n, ptr(b[f"GH{i}"]), ptr(b[f"GXH{i}"]), n,
-              ptr(G.p[f"{bn}.weight"]), ptr(b[f"istd{i}"]), float(self.Bg), ptr(b[f"bns{i}"]), ptr(b[f"GDZ{i}"]), n,
-              ptr(G.g[f"{bn}.weight"]), ptr(G.g[f"{bn}.bias"]), ptr(G.g[f"{lin}.bias"]), 3)
+        args = (s.ptr, s.ns, s.ss, s.ldp, self.B, n, ptr(b[f"GH{i}"]), ptr(b[f"GXH{i}"]), n,
+                ptr(G.p[f"{bn}.weight"]), ptr(b[f"istd{i}"]), float(self.Bg), ptr(b[f"bns{i}"]), ptr(b[f"GDZ{i}"]), n,
+                ptr(G.g[f"{bn}.weight"]), ptr(G.g[f"{bn}.bias"]), ptr(G.g[f"{lin}.bias"]))
+        if not self.exact:
+            p.add(self.L.bn_bwd, *args, 3)
+            return
+        # exact mode: local [sum dy, sum dy*xhat] -> all-reduce -> dz with the global sums.  dgamma / dbeta come out
+        # as the GLOBAL sums on every rank, so they are pre-divided by the world size before the gradient buffer
+        # is summed over ranks.
+        sums, dgam, dbet, w = b[f"bns{i}"], G.g[f"{bn}.weight"], G.g[f"{bn}.bias"], float(self.world)
+        p.add(self.L.bn_bwd, *args, 1)
+        p.host(lambda: self.comm.all_reduce_sum_(sums))
+        p.add(self.L.bn_bwd, *args, 2)
+        if self.world > 1:
+            p.host(lambda: (dgam.div_(w), dbet.div_(w)))
 
     # ------------------------------------------------------------------------------------------------------
     # inputs
@@ -618,12 +663,39 @@ class TrainEngine:
             raise IndexError("index out of bounds in the generator's burst-length mask (model.py:44 semantics)")
 
     def d_stats(self) -> Dict[str, float]:
-        v = self.buf["dstats"].tolist()
+        """Exact mode: the device scalars are per-rank partial sums of global-batch means -> summed over ranks here
+        (a collective: every rank must call it)."""
+        t = self.buf["dstats"]
+        if self.exact:
+            t = self.comm.all_reduce_sum_(t.clone())
+        v = t.tolist()
         return dict(d_loss=v[0], penalty=v[1], w_dist=v[2], mean_rv=v[3], mean_fv=v[4])
 
     def g_stats(self) -> Dict[str, float]:
-        v = self.buf["gstats"].tolist()
+        v = self._g_scalars(self.buf["gstats"])
         return dict(g_loss=v[0], f_loss=v[1], g_combined=v[2], n_sel=int(v[3]))
+
+    def _g_scalars(self, t: torch.Tensor):
+        """[g_loss, f_loss, combined, count].  Exact mode: g_loss and the count are already global on every rank,
+        f_loss is a per-rank partial sum (collective readout)."""
+        if not self.exact:
+            return t.tolist()
+        f = self.comm.all_reduce_sum_(t[1:2].clone())
+        v = t.tolist()
+        v[1] = float(f.item())
+        v[2] = v[0] + self.alpha * v[1]
+        return v
+
+    def epoch_sums(self):
+        """(dacc, gacc): the epoch's running sums of [d_loss, w_dist] and [g_loss, f_loss, combined, #G-steps] (one
+        host sync per epoch; a collective in exact mode)."""
+        d, g = self.buf["dacc"], self.buf["gacc"]
+        if self.exact:
+            return self.comm.all_reduce_sum_(d.clone()).tolist(), self._g_scalars(g)
+        if self.world > 1:          # local-batch losses: report the average over ranks
+            d = self.comm.all_reduce_sum_(d.clone()) / self.world
+            g = self.comm.all_reduce_sum_(g.clone()) / self.world
+        return d.tolist(), g.tolist()
 
     def generator_state(self) -> Dict[str, torch.Tensor]:
         sd = {}
@@ -646,7 +718,7 @@ class TrainEngine:
         self.data_X = X.to(self.dev, torch.float32).contiguous()
         self.data_y = y.to(self.dev, torch.int32).contiguous()
         self.N = self.data_X.shape[0]
-        self.iters_per_epoch = self.N // self.B          # full batches; the trainer handles a ragged tail
+        self.iters_per_epoch = self.N // self.cursor_step    # full (global) batches; the trainer handles a ragged tail
         self.auto_reshuffle = True                       # iteration() starts a new permutation when one is used up
         self._pos = 0
         self.iter_state.zero_()

@@ -4,7 +4,13 @@ src/mlp_df_wgan_train.py (flags :38-54, artefacts :104-112,286-313).
 
     python -m wfd_gan_amd.mlp_df_wgan_train -d <...>/feature/raw_feature_x.npz --f_model df.ckpt [--n_epochs 800 ...]
 
-Additive flags (defaults reproduce the reference): --penalty {div,gp}, --seed, --no_graph.
+Additive flags (defaults reproduce the reference): --penalty {div,gp}, --seed, --no_graph, --dp {strong,weak}.
+
+Multi-GPU: launch with torchrun, one process per GPU (``python -m torch.distributed.run --nproc-per-node N -m
+wfd_gan_amd.mlp_df_wgan_train ...``).  ``--dp strong`` (default) splits every batch of --batch_size rows over the
+ranks with synchronised BatchNorm statistics and a global selected-row count: the update equals the single-GPU one.
+``--dp weak`` gives every rank its own --batch_size rows (DDP semantics: local BatchNorm, averaged gradients).  All
+ranks hold the dataset and the same epoch permutation; rank 0 writes the artefacts.
 Per iteration nothing leaves the GPU: the dataset is resident in HBM, batches / z / dropout masks are produced on
 device, the D-step and G-step are HIP-graph replays, and the epoch's loss sums accumulate in device memory (the
 reference's 2-5 ``.item()`` syncs and per-G-step D2H copies are gone; one sync per epoch reads the sums).
@@ -21,7 +27,7 @@ import torch
 from sklearn import preprocessing
 
 from . import common as cm
-from . import utils
+from . import parallel, utils
 from ._lib import lib
 from .engine import TrainEngine
 from .model import DF, Discriminator, Generator
@@ -54,6 +60,9 @@ def parse_args(argv=None):
                    help="div = W-div (what the reference runs); gp = interpolated WGAN-GP (utils.py:64-84)")
     p.add_argument("--seed", type=int, default=None, help="seed for init / shuffling / device RNG")
     p.add_argument("--no_graph", action="store_true", help="launch kernels eagerly instead of HIP-graph replay")
+    p.add_argument("--dp", choices=["strong", "weak"], default="strong",
+                   help="torchrun launches only: strong = --batch_size is the global batch (SyncBN, result-equal to one "
+                        "GPU); weak = --batch_size rows per GPU (local BatchNorm, averaged gradients)")
     return p.parse_args(argv)
 
 
@@ -69,40 +78,57 @@ def clip_dataset(X: np.ndarray, device) -> np.ndarray:
     return X
 
 
-def df_accuracy(f_model: DF, fakes: torch.Tensor, labels: torch.Tensor) -> float:
-    """test_DF_acc_epoch (:57-79): DF argmax accuracy over this epoch's generated traces, batches of 128."""
+def df_accuracy(f_model: DF, fakes: torch.Tensor, labels: torch.Tensor, comm=None) -> float:
+    """test_DF_acc_epoch (:57-79): DF argmax accuracy over this epoch's generated traces, batches of 128 (summed
+    over the ranks' shares in data-parallel runs)."""
     total, correct = 0, 0
     for a in range(0, fakes.shape[0], 128):
         x = fakes[a:a + 128, 1:]
         pred = f_model(x.reshape(x.shape[0], 1, x.shape[1])).argmax(1)
         correct += int((pred == labels[a:a + 128]).sum())
         total += x.shape[0]
+    if comm is not None and comm.world > 1:
+        t = comm.all_reduce_sum_(torch.tensor([correct, total], dtype=torch.float64, device=fakes.device))
+        correct, total = t.tolist()
     return correct / max(total, 1)
+
+
+class _Quiet:
+    """Stand-in logger of the ranks that do not write the log."""
+    def info(self, *a, **k): pass
+    debug = warning = info
 
 
 def main(argv=None):
     args = parse_args(argv)
     if not torch.cuda.is_available():
         raise SystemExit("wfd_gan_amd needs an MI355X (HIP device); there is no CPU path")
-    device = torch.device(f"cuda:{args.cuda_id}")
+    rank, world, local = parallel.init_from_env()
+    device = torch.device(f"cuda:{local if world > 1 else args.cuda_id}")
     torch.cuda.set_device(device)
     if args.seed is not None:
         torch.manual_seed(args.seed)
         np.random.seed(args.seed)
+    comm = parallel.Comm()
 
-    pardir, modeldir, checkpointdir = utils.init_directory(args.dir, tag="training_{}".format(strftime("%m%d_%H%M%S")))
-    logger = utils.init_logger("gan", join(pardir, "log.txt"))
-    logger.info(args)
-    logger.debug("Output to {}".format(pardir))
-    with open(join(pardir, "args.json"), "wt") as f:
-        json.dump(vars(args), f, indent=4)
+    pardir = modeldir = checkpointdir = None
+    logger = _Quiet()
+    if rank == 0:
+        pardir, modeldir, checkpointdir = utils.init_directory(args.dir,
+                                                               tag="training_{}".format(strftime("%m%d_%H%M%S")))
+        logger = utils.init_logger("gan", join(pardir, "log.txt"))
+        logger.info(args)
+        logger.debug("Output to {}".format(pardir))
+        with open(join(pardir, "args.json"), "wt") as f:
+            json.dump(vars(args), f, indent=4)
 
     X, y = utils.load_dataset(args.dir)
     logger.info("Loaded dataset:{}, min burst:{} max burst:{}, min label:{}, max label:{}"
                 .format(X.shape, X[:, 1:].min(), X[:, 1:].max(), y.min(), y.max()))
     if args.clip:
         X = clip_dataset(X, device)
-        np.savez_compressed(args.dir.split(".npz")[0] + "_clip.npz", features=X, labels=y)
+        if rank == 0:
+            np.savez_compressed(args.dir.split(".npz")[0] + "_clip.npz", features=X, labels=y)
         logger.info("Save back  the clipped dataset to {}".format(args.dir.split(".npz")[0] + "_clip.npz"))
     y = y - y.min()
 
@@ -121,22 +147,39 @@ def main(argv=None):
     f_model.load_state_dict(torch.load(args.f_model, map_location="cpu", weights_only=True))
     f_model.eval().to(device)
 
-    B = min(args.batch_size, N)
+    exact = world > 1 and args.dp == "strong"
+    if exact and min(args.batch_size, N) % world:
+        raise SystemExit(f"--dp strong needs --batch_size divisible by the number of ranks ({world})")
+    B = min(args.batch_size, N) // (world if exact else 1)        # rows per rank
+    Bg = B * world                                                # rows per iteration over all ranks
     seed = args.seed if args.seed is not None else int(torch.initial_seed() & 0x7FFFFFFF)
+    if world > 1:       # one seed for the permutation on every rank (rank 0's); the device RNG streams differ per rank
+        t = torch.tensor([seed], dtype=torch.int64, device=device)
+        parallel.broadcast_state_([t])
+        seed = int(t.item())
+    dp = dict(world_size=world, rank=rank, sync_bn=exact)
+    rng_seed = seed + 1000003 * rank
     eng = TrainEngine(seq_len, class_dim, args.latent_dim, B, scaler.data_min_[0], scaler.data_max_[0],
                       generator.state_dict(), discriminator.state_dict(), f_model.state_dict(), lr=args.lr,
                       alpha=args.alpha, n_critic=args.n_critic, penalty=args.penalty, lambda_gp=cm.lambda_gp,
-                      device=device, seed=seed)
+                      device=device, seed=rng_seed, **dp)
+    if world > 1:       # identical replicas whatever the host seeding was
+        parallel.broadcast_state_([eng.Gp.flat, eng.Dp.flat] + list(eng.Gbuf.values()))
     eng.attach_dataset(torch.from_numpy(Xs), torch.from_numpy(y), shuffle_seed=seed)
     eng.auto_reshuffle = False        # the epoch loop below owns the permutation (ragged last batch)
     if not args.no_graph:
         eng.capture_graphs()
-    n_full, tail_rows = N // B, N % B
+    n_full, tail_global = N // Bg, N % Bg
+    tail_rows = tail_global // world
     tail = None
-    if tail_rows > 1:       # the DataLoader's ragged last batch (drop_last=False); BatchNorm needs > 1 row
+    # the DataLoader's ragged last batch (drop_last=False); BatchNorm needs > 1 row.  Data-parallel runs keep it only
+    # when it splits evenly over the ranks.
+    if tail_rows > 1 and tail_global % world == 0:
         tail = TrainEngine(seq_len, class_dim, args.latent_dim, tail_rows, scaler.data_min_[0], scaler.data_max_[0],
                            {}, {}, {}, lr=args.lr, alpha=args.alpha, n_critic=args.n_critic, penalty=args.penalty,
-                           lambda_gp=cm.lambda_gp, device=device, seed=seed + 1, share=eng)
+                           lambda_gp=cm.lambda_gp, device=device, seed=rng_seed + 1, share=eng, **dp)
+    elif tail_global:
+        logger.info("dropping the last {} rows of every epoch (ragged batch)".format(tail_global))
     n_batches = n_full + (1 if tail is not None else 0)
     n_gsteps = (n_batches + args.n_critic - 1) // args.n_critic
     cap = n_gsteps * B
@@ -153,9 +196,9 @@ def main(argv=None):
             do_g = (i % args.n_critic == 0)
             if i < n_full:
                 eng.iteration(i)
-                src, rows, idx = eng, B, eng.perm[i * B:(i + 1) * B]
+                src, rows, idx = eng, B, eng.perm[i * Bg + rank * B: i * Bg + (rank + 1) * B]
             else:
-                idx = eng.perm[n_full * B:]
+                idx = eng.perm[n_full * Bg + rank * tail_rows: n_full * Bg + (rank + 1) * tail_rows]
                 tail.set_batch(eng.data_X[idx], y_dev[idx], torch.zeros(tail_rows, args.latent_dim))
                 tail.draw_z()
                 tail.draw_masks(do_g)
@@ -169,21 +212,26 @@ def main(argv=None):
                 fill += rows
         eng.reshuffle()
         eng.check_length_index()
-        dacc, gacc = eng.buf["dacc"].tolist(), eng.buf["gacc"].tolist()      # the epoch's only host sync
+        dacc, gacc = eng.epoch_sums()                     # the epoch's only host sync (and loss collective)
         d_ep, w_ep = dacc[0] / n_batches, dacc[1] / n_batches
         div_g = max(n_batches // args.n_critic, 1)
         g_ep, f_ep, comb_ep = gacc[0] / div_g, gacc[1] / div_g, gacc[2] / div_g
-        df_acc = df_accuracy(f_model, ep_fake[:fill], y_dev[ep_idx[:fill]])
+        df_acc = df_accuracy(f_model, ep_fake[:fill], y_dev[ep_idx[:fill]], comm)
         logger.info(
             "[Epoch %2d/%2d] [D loss: %.4f] [G loss: %.4f + %.4f * %.4f = %.4f] [DF acc: %.4f] [w dist: %.4f]"
             % (epoch + 1, args.n_epochs, d_ep, g_ep, args.alpha, f_ep, comb_ep, df_acc, w_ep))
         stop = w_ep <= w_dist_threshold and df_acc >= 0.9
         if epoch == 0 or (epoch + 1) % args.freq == 0 or stop:
-            sel = ep_idx[:fill].cpu().numpy()
-            total_real = scaler.inverse_transform(Xs[sel])                               # float64
-            total_fake = scaler.inverse_transform(ep_fake[:fill].cpu().numpy())          # float32
-            np.savez_compressed(join(checkpointdir, "epoch_{}".format(epoch + 1)), x=total_real, recon_x=total_fake,
-                                label=y[sel])
+            idx_all, fake_all = ep_idx[:fill], ep_fake[:fill]
+            if world > 1:                                 # every rank's share of the epoch's generated traces
+                idx_all = comm.all_gather(idx_all).reshape(-1)
+                fake_all = comm.all_gather(fake_all).reshape(-1, seq_len)
+            if rank == 0:
+                sel = idx_all.cpu().numpy()
+                total_real = scaler.inverse_transform(Xs[sel])                           # float64
+                total_fake = scaler.inverse_transform(fake_all.cpu().numpy())            # float32
+                np.savez_compressed(join(checkpointdir, "epoch_{}".format(epoch + 1)), x=total_real,
+                                    recon_x=total_fake, label=y[sel])
         losses["generator"].append(g_ep)
         losses["discriminator"].append(d_ep)
         losses["dist"].append(w_ep)
@@ -191,6 +239,8 @@ def main(argv=None):
             logger.info("Early stopping since the w-dist = {}, df acc = {}.".format(w_ep, df_acc))
             break
 
+    if rank != 0:
+        return None
     np.savez_compressed(join(checkpointdir, "loss.npz"), generator=losses["generator"],
                         discriminator=losses["discriminator"], dist=losses["dist"])
     torch.save({k: v.cpu() for k, v in eng.generator_state().items()},

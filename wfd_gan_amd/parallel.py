@@ -20,8 +20,8 @@ def init_from_env(backend: Optional[str] = None) -> Tuple[int, int, int]:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        if backend is None:
-            backend = "nccl" if torch.cuda.is_available() else "gloo"
+        if backend is None:     # WFD_DIST_BACKEND=gloo: test rigs where several ranks share one GPU
+            backend = os.environ.get("WFD_DIST_BACKEND") or ("nccl" if torch.cuda.is_available() else "gloo")
         dist.init_process_group(backend=backend, rank=rank, world_size=world)
     return rank, world, local
 
@@ -32,6 +32,58 @@ def allreduce_sum_(flat: torch.Tensor, group=None) -> torch.Tensor:
     return flat
 
 
+class Comm:
+    """The small collectives of the exact (global-batch) data-parallel mode on device tensors: BatchNorm statistics,
+    BatchNorm backward sums, the selected-row count, loss scalars.  With RCCL ("nccl") they run in place on the
+    device; with "gloo" (CPU tests, or several test ranks sharing one GPU) device tensors are staged through the
+    host.  Without an initialised process group every call is the identity (world 1)."""
+
+    def __init__(self, group=None):
+        self.group = group
+        self.active = dist.is_available() and dist.is_initialized()
+        self.world = dist.get_world_size(group) if self.active else 1
+        self.rank = dist.get_rank(group) if self.active else 0
+        self.staged = self.active and dist.get_backend(group) == "gloo"
+
+    def all_reduce_sum_(self, t: torch.Tensor) -> torch.Tensor:
+        if not self.active:
+            return t
+        if self.staged and t.is_cuda:
+            h = t.detach().cpu()
+            dist.all_reduce(h, op=dist.ReduceOp.SUM, group=self.group)
+            t.copy_(h)
+        else:
+            dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group)
+        return t
+
+    def all_gather(self, t: torch.Tensor) -> torch.Tensor:
+        """(world, *t.shape), rank-major."""
+        if not self.active:
+            return t.unsqueeze(0).clone()
+        src = t.detach().cpu().contiguous() if (self.staged and t.is_cuda) else t.contiguous()
+        out = torch.empty((self.world,) + tuple(src.shape), dtype=src.dtype, device=src.device)
+        if self.staged:
+            parts = [torch.empty_like(src) for _ in range(self.world)]
+            dist.all_gather(parts, src, group=self.group)
+            out = torch.stack(parts)
+        else:
+            dist.all_gather_into_tensor(out, src, group=self.group)
+        return out.to(t.device)
+
+    def combine_bn_stats_(self, mean: torch.Tensor, m2: torch.Tensor, rows_per_rank: int) -> None:
+        """Per-feature (mean, M2 = sum (x - mean)^2) of equal-sized row shards -> the same pair over all rows
+        (pairwise update of Chan et al.): mean = avg(mean_r); M2 = sum M2_r + rows * sum (mean_r - mean)^2.  Every
+        rank computes the identical result from the identical gathered operands."""
+        if self.world == 1:
+            return
+        n = mean.numel()
+        allp = self.all_gather(torch.cat([mean, m2]))
+        means, m2s = allp[:, :n], allp[:, n:]
+        mu = means.sum(0) / self.world
+        mean.copy_(mu)
+        m2.copy_(m2s.sum(0) + float(rows_per_rank) * ((means - mu) ** 2).sum(0))
+
+
 class GradSync:
     """Bucketed gradient all-reduce that overlaps with the rest of the backward: ``start(bucket)`` launches an
     asynchronous sum over a slice of the flat gradient buffer as soon as that slice is final, ``finish()`` makes
@@ -40,8 +92,17 @@ class GradSync:
     def __init__(self, group=None):
         self.group = group
         self.pending = []
+        self.active = dist.is_available() and dist.is_initialized()
+        self.staged = self.active and dist.get_backend(group) == "gloo"
 
     def start(self, bucket: torch.Tensor):
+        if not self.active:                         # world 1 without a process group: the sum is the bucket itself
+            return
+        if self.staged and bucket.is_cuda:          # test configuration: ranks sharing a GPU over gloo
+            h = bucket.detach().cpu()
+            dist.all_reduce(h, op=dist.ReduceOp.SUM, group=self.group)
+            bucket.copy_(h)
+            return
         self.pending.append(dist.all_reduce(bucket, op=dist.ReduceOp.SUM, group=self.group, async_op=True))
 
     def finish(self):
@@ -77,5 +138,11 @@ def sum_over_ranks(value: float, device) -> float:
 def broadcast_state_(tensors: List[torch.Tensor], src: int = 0, group=None) -> None:
     """Make replicas identical at start-up (parameters, optimizer state, BN buffers)."""
     if dist.is_available() and dist.is_initialized():
+        staged = dist.get_backend(group) == "gloo"
         for t in tensors:
-            dist.broadcast(t, src=src, group=group)
+            if staged and t.is_cuda:
+                h = t.detach().cpu()
+                dist.broadcast(h, src=src, group=group)
+                t.copy_(h)
+            else:
+                dist.broadcast(t, src=src, group=group)
