@@ -220,6 +220,13 @@ int wfd_clip_bursts(double* X, long N, int S, double max_len, double max_out, do
 int wfd_sample_post(const float* Y, int ldy, int M, int S, const double* min_, const double* scale_, int* out, int ldo,
                     int* len_out, void* stream);
 
+/* the same epilogue for the generator's other consumers.  mode 0: generate.py:59-63 (= wfd_sample_post);
+ * 1: WTGAN.get_ref_trace, src/gan_wt.py:79-87 (count from element 0, made even, rint, 0 -> 1; element 0 not emitted);
+ * 2: query_from_gan, src/gan_glue.py:114-124 (truncating cast, trailing zeros trimmed, even length, <= 0 -> 1,
+ *    alternating signs); 3: sample_trace, src/synthesize.py:86-90 (rint first, then trim zeros at both ends). */
+int wfd_sample_post_mode(const float* Y, int ldy, int M, int S, const double* min_, const double* scale_, int mode, int* out,
+                         int ldo, int* len_out, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -420,6 +420,42 @@ def sample_postprocess(row32: np.ndarray, scale: np.ndarray, min_: np.ndarray) -
     return x
 
 
+def sample_postprocess_wt(row32: np.ndarray, scale: np.ndarray, min_: np.ndarray) -> np.ndarray:
+    """WTGAN.get_ref_trace, src/gan_wt.py:79-87: burst count from element 0 (truncated, capped at S-1, made even),
+    then round-half-even of the next ``length`` elements, 0 -> 1.  Element 0 itself is not part of the output."""
+    x = inverse_transform_f32(row32.reshape(1, -1), scale, min_).flatten()
+    length = min(int(x[0]), len(x) - 1)
+    if length % 2 != 0:
+        length -= 1
+    x = np.round(x[1:1 + length]).astype(int)
+    return np.where(x == 0, 1, x)
+
+
+def sample_postprocess_glue(row32: np.ndarray, scale: np.ndarray, min_: np.ndarray) -> np.ndarray:
+    """query_from_gan, src/gan_glue.py:114-124: ``length = int(x0)`` elements after the first, TRUNCATED to int,
+    trailing zeros trimmed, odd length drops its last element, values <= 0 become 1, signs alternate +,-."""
+    x = inverse_transform_f32(row32.reshape(1, -1), scale, min_).flatten()
+    length = int(x[0])
+    x = x[1:1 + length].astype(int)
+    x = np.trim_zeros(x, trim="b")
+    if len(x) % 2 == 1:
+        x = x[:-1]
+    x[x <= 0] = 1
+    return np.tile([1, -1], len(x) // 2) * x
+
+
+def sample_postprocess_synth(row32: np.ndarray, scale: np.ndarray, min_: np.ndarray) -> np.ndarray:
+    """sample_trace, src/synthesize.py:86-90 (n = 1): round-half-even of the whole row to int FIRST, then
+    np.trim_zeros at both ends; interior zeros stay 0."""
+    x = inverse_transform_f32(row32.reshape(1, -1), scale, min_)
+    x = np.round(x).astype(int).flatten()
+    return np.trim_zeros(x)
+
+
+POSTPROCESS = {"generate": sample_postprocess, "wt": sample_postprocess_wt, "glue": sample_postprocess_glue,
+               "synth": sample_postprocess_synth}
+
+
 def sample(st_G: Dict[str, torch.Tensor], c_ind: int, z: np.ndarray, class_dim: int, scaler_min, scaler_max,
            scale: np.ndarray, min_: np.ndarray) -> np.ndarray:
     """sample(), src/generate.py:48-64, with z supplied (the reference draws np.random.randn(1, Z))."""

@@ -18,7 +18,9 @@ What it does
   5. PIN D: reference-style sampling (generate.py:48-64 call sequence around the reference Generator and a real
      sklearn MinMaxScaler) == oracle.sample,
   6. PIN E: the reference's utils.compute_gradient_penalty (WGAN-GP, src/utils.py:64-84) == oracle.wgan_gp_penalty,
-  7. writes the fixtures (inputs, masks as packed bits, expected outputs).  Weights are NOT stored: tests
+  7. PIN F: the other consumers' integer epilogues (gan_wt.py:79-87, gan_glue.py:114-124, synthesize.py:86-90), run
+     by the reference's own functions == oracle.POSTPROCESS[...],
+  8. writes the fixtures (inputs, masks as packed bits, expected outputs).  Weights are NOT stored: tests
      re-derive them from the seed with oracle.make_state and check the stored checksums.
 """
 import argparse
@@ -336,6 +338,114 @@ def make_sampler_case(ref_model, name, seq_len, class_dim, latent_dim, n_cases, 
 
 
 # ------------------------------------------------------------------------------------------------
+class _FixedRowModel:
+    """Stands where the consumers expect ``model``: eval() and __call__(z, c) -> the given generator output row."""
+    def __init__(self, row):
+        self.row = np.asarray(row, dtype=np.float32).reshape(1, -1)
+
+    def eval(self):
+        return self
+
+    def __call__(self, z, c):
+        return torch.from_numpy(self.row.copy())
+
+
+def _reference_consumers():
+    """The three other consumers of the generator in the reference, each returning its integer epilogue for the
+    generator output row that ``model`` yields:
+      wt    : gan_wt.WTGAN.get_ref_trace (imported module, object built without its file-loading constructor)
+      synth : synthesize.sample_trace    (imported module, its globals set)
+      glue  : gan_glue.query_from_gan    -- gan_glue imports the absent KDEpy at module top, so only this function's
+              definition is taken from the file (ast) and executed with the globals it reads."""
+    import ast
+    import gan_wt
+    import synthesize
+
+    def wt(model, scaler, seq_len, class_dim, latent_dim):
+        o = gan_wt.WTGAN.__new__(gan_wt.WTGAN)
+        o.model, o.scaler, o.seq_len, o.class_dim, o.latent_dim = model, scaler, seq_len, class_dim, latent_dim
+        return np.asarray(o.get_ref_trace(), dtype=np.int64)
+
+    def synth(model, scaler, seq_len, class_dim, latent_dim):
+        synthesize.model, synthesize.scaler = model, scaler
+        synthesize.latent_dim, synthesize.class_dim = latent_dim, class_dim
+        return np.asarray(synthesize.sample_trace(0), dtype=np.int64)
+
+    path = os.path.join(REF_SRC, "gan_glue.py")
+    tree = ast.parse(open(path).read(), filename=path)
+    fn = [n for n in tree.body if isinstance(n, ast.FunctionDef) and n.name == "query_from_gan"]
+    assert len(fn) == 1
+    code = compile(ast.Module(body=fn, type_ignores=[]), path, "exec")
+
+    def glue(model, scaler, seq_len, class_dim, latent_dim):
+        ns = dict(np=np, torch=torch, device=torch.device("cpu"), model=model, latent_dim=latent_dim, scaler=scaler,
+                  cls_num=class_dim)
+        exec(code, ns)
+        return np.asarray(ns["query_from_gan"](0), dtype=np.int64)
+
+    return dict(wt=wt, glue=glue, synth=synth)
+
+
+def make_postprocess_modes(ref_model):
+    """PIN F + fixture: the integer epilogues of gan_wt.py:79-87, gan_glue.py:114-124 and synthesize.py:86-90, run
+    by the reference's own functions on (a) real generator outputs and (b) adversarial rows, vs the oracle."""
+    from sklearn import preprocessing
+    print("[sampler modes] gan_wt / gan_glue / synthesize epilogues")
+    consumers = _reference_consumers()
+    seq_len, class_dim, latent_dim, seed = 61, 5, 16, 41
+    L = seq_len - 1
+    X, y = O.synth_dataset(class_dim, 8, L, 4, 75, 179, seed=seed)
+    X[:, 7] = 3.0                                   # constant column: scale_ = 1
+    scaler = preprocessing.MinMaxScaler()
+    scaler.fit(X)
+    scale, min_ = O.scaler_params(scaler.data_min_, scaler.data_max_)
+    torch.manual_seed(seed)
+    G = ref_model.Generator(seq_len, class_dim, latent_dim, scaler_min=scaler.data_min_[0],
+                            scaler_max=scaler.data_max_[0], is_gpu=False)
+    G.eval()
+    rows = []
+    zr = np.random.RandomState(seed + 2)
+    with torch.no_grad():
+        for i in range(40):
+            c = torch.zeros(1, class_dim)
+            c[:, zr.randint(class_dim)] = 1
+            rows.append(G(torch.from_numpy(zr.randn(1, latent_dim).astype("float32")), c).numpy()[0])
+    r = np.random.RandomState(seed + 3)
+    for i in range(48):         # adversarial: exact .5 values, zeros inside / at the ends, odd and even counts, short rows
+        row = np.zeros(seq_len, dtype=np.float32)
+        n = int(r.randint(0, seq_len))
+        tgt = r.randint(0, 30, seq_len).astype(np.float64) + 0.5 * (r.rand(seq_len) < 0.5)
+        tgt[0] = n + (0.75 if i % 3 == 0 else 0.0)          # fractional burst count: int() truncates
+        if i % 8 == 7:
+            tgt[0] = seq_len + 5                            # count beyond the row
+        full = ((tgt * scale) + min_).astype(np.float32)
+        m = min(n + 1, seq_len)
+        row[:m] = full[:m]
+        if i % 4 == 1 and m > 2:
+            row[m - 1] = min_[m - 1]                        # trailing value that inverse-transforms to 0
+        if i % 4 == 2 and m > 3:
+            row[m // 2] = min_[m // 2]
+        if i == 47:
+            row[:] = 0.0
+        rows.append(row)
+    rows = np.stack(rows).astype(np.float32)
+    fx = dict(rows=rows, data_min=scaler.data_min_, data_max=scaler.data_max_)
+    for mode, ref_fn in consumers.items():
+        outs = []
+        for i, row in enumerate(rows):
+            np.random.seed(i)
+            want = ref_fn(_FixedRowModel(row), scaler, seq_len, class_dim, latent_dim)
+            mine = O.POSTPROCESS[mode](row, scale, min_)
+            assert np.array_equal(want, mine), (mode, i, want, mine)
+            outs.append(want)
+        fx[f"{mode}_out"] = np.stack([np.pad(o, (0, seq_len - len(o))) for o in outs]).astype(np.int64)
+        fx[f"{mode}_len"] = np.array([len(o) for o in outs])
+        print(f"   {mode}: {len(outs)} rows bit-exact (lengths {fx[f'{mode}_len'].min()}..{fx[f'{mode}_len'].max()})")
+    np.savez_compressed(os.path.join(HERE, "sampler_modes.npz"), **fx)
+    print("   wrote sampler_modes.npz")
+
+
+# ------------------------------------------------------------------------------------------------
 def pin_script_end_to_end():
     """PIN C: unmodified reference trainer (runpy) vs oracle.train_loop.run_training, same seeds."""
     print("[script] running the unmodified reference trainer end-to-end (tiny config-1-like dataset)")
@@ -452,6 +562,8 @@ def main():
     if not args.only or args.only == "sampler":
         make_sampler_case(ref_model, "cfg2", 1401, 100, 500, 100, seed=31)
         make_sampler_case(ref_model, "tiny", 41, 5, 16, 50, seed=32)
+    if not args.only or args.only == "modes":
+        make_postprocess_modes(ref_model)
     if not args.only or args.only == "gp":
         pin_gradient_penalty(ref_model)
     if not args.skip_script and (not args.only or args.only == "script"):

@@ -64,6 +64,16 @@ def test_oracle_sampler_matches_reference_fixture(name):
         assert np.array_equal(got, fx["adv_out"][i][: fx["adv_len"][i]]), i
 
 
+@pytest.mark.parametrize("mode", ["wt", "glue", "synth"])
+def test_oracle_epilogue_modes_match_reference_fixture(mode):
+    """gan_wt / gan_glue / synthesize epilogues: outputs of the reference's own functions (PIN F)."""
+    fx = np.load(os.path.join(GOLDEN, "sampler_modes.npz"))
+    scale, min_ = O.scaler_params(fx["data_min"], fx["data_max"])
+    for i, row in enumerate(fx["rows"]):
+        got = O.POSTPROCESS[mode](row, scale, min_)
+        assert np.array_equal(got, fx[f"{mode}_out"][i][: fx[f"{mode}_len"][i]]), (mode, i)
+
+
 def test_my_clip_matches_rowwise_definition():
     rng = np.random.default_rng(0)
     X = rng.integers(0, 700, size=(50, 41)).astype(np.float64)

@@ -139,6 +139,36 @@ def test_sample_post_bit_exact(name):
         assert np.array_equal(out.cpu().numpy().astype(np.int64), fx[key_out]), key_out
 
 
+@pytest.mark.parametrize("mode", ["generate", "wt", "glue", "synth"])
+def test_sample_post_modes_bit_exact(mode):
+    """The epilogues of the generator's other consumers (gan_wt.py:79-87, gan_glue.py:114-124, synthesize.py:86-90)
+    against what the reference's own functions returned for the same generator output rows (tests/golden PIN F);
+    mode "generate" against the oracle restatement on those rows."""
+    from oracle import wfdgan_oracle as O
+    from wfd_gan_amd._lib import lib
+    from wfd_gan_amd.sampler import POST_MODES, minmax_params
+    L = lib()
+    fx = np.load(os.path.join(GOLDEN, "sampler_modes.npz"))
+    scale, min_ = minmax_params(fx["data_min"], fx["data_max"])
+    sd, md = torch.from_numpy(scale).to(DEV), torch.from_numpy(min_).to(DEV)
+    Y = torch.from_numpy(fx["rows"]).to(DEV).contiguous()
+    M, S = Y.shape
+    out = torch.full((M, S), -7, dtype=torch.int32, device=DEV)
+    lens = torch.zeros(M, dtype=torch.int32, device=DEV)
+    L.sample_post_mode(Y.data_ptr(), S, M, S, md.data_ptr(), sd.data_ptr(), POST_MODES[mode], out.data_ptr(), S,
+                       lens.data_ptr(), torch.cuda.current_stream().cuda_stream)
+    torch.cuda.synchronize()
+    got, gl = out.cpu().numpy().astype(np.int64), lens.cpu().numpy()
+    for i in range(M):
+        if mode == "generate":
+            want = O.sample_postprocess(fx["rows"][i], scale, min_)
+        else:
+            want = fx[f"{mode}_out"][i][: fx[f"{mode}_len"][i]]
+        assert gl[i] == len(want), (mode, i)
+        assert np.array_equal(got[i, : gl[i]], want), (mode, i)
+        assert not got[i, gl[i]:].any()
+
+
 @pytest.mark.parametrize("name", ["tiny", "cfg2"])
 def test_bulk_sampler_end_to_end(name):
     """(seed, class) -> integer burst vector through the HIP generator.  The fp32 GEMMs sum in a different order

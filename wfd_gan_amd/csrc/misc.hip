@@ -209,6 +209,64 @@ __global__ void sample_post_kernel(const float* __restrict__ Y, int ldy, int S, 
     if (threadIdx.x == 0) len_out[m] = n;
 }
 
+
+// The sampler epilogues of the generator's other consumers, selected by `mode` (x = inverse_transform(y) as above):
+//   0 generate.py:59-63      trim zeros of x at both ends, rint, 0 -> 1                      (= sample_post_kernel)
+//   1 gan_wt.py:79-87        len = min(int(x0), S-1) made even; out = rint(x[1 .. 1+len)), 0 -> 1
+//   2 gan_glue.py:114-124    len = int(x0); v = trunc(x[1 .. 1+len)); trim trailing zeros of v; odd length drops the
+//                            last; v <= 0 -> 1; signs alternate +,-
+//   3 synthesize.py:86-90    v = rint(x) over the whole row; trim zeros of v at both ends (interior zeros stay)
+// A negative burst count (outside the reference's domain: counts are >= 0) is treated as 0.
+__global__ void sample_post_mode_kernel(const float* __restrict__ Y, int ldy, int S, const double* __restrict__ min_,
+                                        const double* __restrict__ scale_, int mode, int* __restrict__ out, int ldo,
+                                        int* __restrict__ len_out) {
+    extern __shared__ float xs[];
+    __shared__ int s_lo, s_hi;
+    const int m = blockIdx.x;
+    if (threadIdx.x == 0) { s_lo = S; s_hi = -1; }
+    for (int j = threadIdx.x; j < S; j += blockDim.x) {
+        float x = (float)((double)Y[(long)m * ldy + j] - min_[j]);
+        xs[j] = (float)((double)x / scale_[j]);
+    }
+    __syncthreads();
+    int cnt = (int)xs[0];                       // int(x0): truncation
+    cnt = cnt < 0 ? 0 : (cnt > S - 1 ? S - 1 : cnt);
+    // candidate window [a, b) and the non-zero test that drives the trimming
+    const int a = (mode == 1 || mode == 2) ? 1 : 0;
+    const int b = (mode == 1 || mode == 2) ? 1 + cnt : S;
+    int lo = S, hi = -1;
+    if (mode != 1)
+        for (int j = a + threadIdx.x; j < b; j += blockDim.x) {
+            const float x = xs[j];
+            const bool nz = mode == 0 ? (x != 0.f) : (mode == 2 ? ((int)x != 0) : ((int)rintf(x) != 0));
+            if (nz) { lo = min(lo, j); hi = max(hi, j); }
+        }
+    atomicMin(&s_lo, lo);
+    atomicMax(&s_hi, hi);
+    __syncthreads();
+    lo = s_lo; hi = s_hi;
+    int first, n;
+    if (mode == 1) { first = 1; n = cnt & ~1; }
+    else if (mode == 2) { first = 1; n = hi >= 1 ? hi : 0; n &= ~1; }
+    else { first = lo; n = hi >= lo ? hi - lo + 1 : 0; }
+    for (int j = threadIdx.x; j < S; j += blockDim.x) {
+        int v = 0;
+        if (j < n) {
+            const float x = xs[first + j];
+            if (mode == 2) {
+                v = (int)x;
+                if (v <= 0) v = 1;
+                if (j & 1) v = -v;
+            } else {
+                v = (int)rintf(x);
+                if (mode != 3 && v == 0) v = 1;
+            }
+        }
+        out[(long)m * ldo + j] = v;
+    }
+    if (threadIdx.x == 0) len_out[m] = n;
+}
+
 }  // namespace
 
 extern "C" {
@@ -300,6 +358,16 @@ int wfd_clip_bursts(double* X, long N, int S, double max_len, double max_out, do
     if (blocks > 4096) blocks = 4096;
     hipLaunchKernelGGL(clip_bursts_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, X, N, S, max_len,
                        max_out, max_in);
+    WFD_CHECK_LAUNCH();
+    return WFD_OK;
+}
+
+int wfd_sample_post_mode(const float* Y, int ldy, int M, int S, const double* min_, const double* scale_, int mode, int* out,
+                         int ldo, int* len_out, void* stream) {
+    if (!Y || !min_ || !scale_ || !out || !len_out || M <= 0 || S <= 0 || ldy < S || ldo < S) return WFD_ERR_ARG;
+    if (mode < 0 || mode > 3 || (size_t)S * sizeof(float) > 60000) return WFD_ERR_ARG;
+    hipLaunchKernelGGL(sample_post_mode_kernel, dim3(M), dim3(256), (size_t)S * sizeof(float), (hipStream_t)stream, Y, ldy,
+                       S, min_, scale_, mode, out, ldo, len_out);
     WFD_CHECK_LAUNCH();
     return WFD_OK;
 }

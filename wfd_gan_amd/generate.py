@@ -44,11 +44,15 @@ def parse_args(argv=None):
     p.add_argument("--out", default=None, help="npz to write (traces int32 zero-padded, lens, labels)")
     p.add_argument("--operands", choices=["f32", "bf16"], default="f32",
                    help="f32 = exact-fp32 MFMA (parity path); bf16 = bf16-operand MFMA (about 3.7x faster, not bit-exact)")
+    p.add_argument("--mode", choices=["generate", "wt", "glue", "synth"], default="generate",
+                   help="integer epilogue: generate.py:59-63 (default), gan_wt.py:79-87, gan_glue.py:114-124 (signed), "
+                        "synthesize.py:86-90")
     return p.parse_args(argv)
 
 
 class TraceSampler:
-    def __init__(self, mdir: str, device="cuda:0", chunk: int = 8192, seed: int = 0, operands: str = "f32"):
+    def __init__(self, mdir: str, device="cuda:0", chunk: int = 8192, seed: int = 0, operands: str = "f32",
+                 mode: str = "generate"):
         scaler = joblib.load(join(mdir, "scaler.gz"))          # our own training artefact (sklearn MinMaxScaler)
         paths = glob.glob(join(mdir, "generator*.ckpt"))
         assert len(paths) == 1, f"expected exactly one generator checkpoint in {mdir}"
@@ -57,7 +61,7 @@ class TraceSampler:
         sd = torch.load(paths[0], map_location="cpu", weights_only=True)
         self.scaler = scaler
         self.bulk = BulkSampler(sd, self.seq_len, self.class_dim, self.latent_dim, scaler.data_min_, scaler.data_max_,
-                                chunk=chunk, device=device, seed=seed, operands=operands)
+                                chunk=chunk, device=device, seed=seed, operands=operands, mode=mode)
         self._one = None
         self._sd, self._dev, self._seed = sd, device, seed
 
@@ -84,7 +88,7 @@ def main(argv=None):
     rank, world, local = parallel.init_from_env()
     torch.cuda.set_device(local)
     ts = TraceSampler(args.model, device=f"cuda:{local}", chunk=args.chunk, seed=args.seed + rank,
-                      operands=args.operands)
+                      operands=args.operands, mode=args.mode)
     a, b = parallel.shard_rows(args.n, rank, world)
     labels = torch.arange(a, b) % ts.class_dim
     out, lens = ts.sample_many(labels)

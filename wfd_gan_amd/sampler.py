@@ -24,16 +24,23 @@ def minmax_params(data_min: np.ndarray, data_max: np.ndarray) -> Tuple[np.ndarra
     return scale, 0.0 - np.asarray(data_min, dtype=np.float64) * scale
 
 
+POST_MODES = {"generate": 0, "wt": 1, "glue": 2, "synth": 3}
+
+
 class BulkSampler:
     def __init__(self, G_state: Dict[str, torch.Tensor], seq_len: int, class_dim: int, latent_dim: int,
                  data_min: np.ndarray, data_max: np.ndarray, chunk: int = 8192, device="cuda:0", seed: int = 0,
-                 operands: str = "f32"):
-        """operands = "f32": exact-fp32 MFMA (the parity path: integers match the reference except at rounding
+                 operands: str = "f32", mode: str = "generate"):
+        """mode selects the integer epilogue: "generate" (src/generate.py:59-63), "wt" (gan_wt.py:79-87), "glue"
+        (gan_glue.py:114-124, signed bursts) or "synth" (synthesize.py:86-90).
+        operands = "f32": exact-fp32 MFMA (the parity path: integers match the reference except at rounding
         boundaries); "bf16": bf16-operand MFMA for the four Linear layers (weights and hidden activations rounded to
         bf16, fp32 accumulate and epilogues) -- several times faster, values within ~1e-2 of the fp32 path."""
         if operands not in ("f32", "bf16"):
             raise ValueError("operands must be 'f32' or 'bf16'")
-        self.operands = operands
+        if mode not in POST_MODES:
+            raise ValueError(f"mode must be one of {sorted(POST_MODES)}")
+        self.operands, self.mode = operands, mode
         if not torch.cuda.is_available():
             raise RuntimeError("wfd_gan_amd.BulkSampler needs a HIP device: there is no CPU path")
         self.L = lib()
@@ -97,8 +104,7 @@ class BulkSampler:
                   0)
             p.add(L.ep_sigmoid_lenmask, ptr(self.ws), 1, 0, ldp, M, S, ptr(self.b8), self.srange, self.smin, ptr(self.y),
                   self.ldy, ptr(self.idx), ptr(self.err))
-            p.add(L.sample_post, ptr(self.y), self.ldy, M, S, ptr(self.min_d), ptr(self.scale_d), ptr(self.out), S,
-                  ptr(self.lens))
+            self._post(p)
             return pr, p
         p.gemm_affine(NT, self.zin, self.ldz, self.w[0], Z + C, M, 512, Z + C, None, self.b0, ACT_RELU, self.h1, 512)
         p.gemm_affine(NT, self.h1, 512, self.w[1], 512, M, 1024, 512, self.aff[0][0], self.aff[0][1], ACT_RELU,
@@ -108,9 +114,17 @@ class BulkSampler:
         s = p.gemm(NT, self.h3, 2048, self.w[3], 2048, M, S, 2048)
         p.add(self.L.ep_sigmoid_lenmask, s.ptr, s.ns, s.ss, s.ldp, M, S, ptr(self.b8), self.srange, self.smin,
               ptr(self.y), self.ldy, ptr(self.idx), ptr(self.err))
-        p.add(self.L.sample_post, ptr(self.y), self.ldy, M, S, ptr(self.min_d), ptr(self.scale_d), ptr(self.out), S,
-              ptr(self.lens))
+        self._post(p)
         return pr, p
+
+    def _post(self, p: Plan):
+        S, M = self.S, self.M
+        if self.mode == "generate":
+            p.add(self.L.sample_post, ptr(self.y), self.ldy, M, S, ptr(self.min_d), ptr(self.scale_d), ptr(self.out), S,
+                  ptr(self.lens))
+        else:
+            p.add(self.L.sample_post_mode, ptr(self.y), self.ldy, M, S, ptr(self.min_d), ptr(self.scale_d),
+                  POST_MODES[self.mode], ptr(self.out), S, ptr(self.lens))
 
     def capture(self):
         side = torch.cuda.Stream(device=self.dev)
