@@ -48,7 +48,7 @@ def test_ep_lrelu_drop_and_mul(cfg):
     assert (o2.cpu().double() - raw * want_d * rs.double()[:, None]).abs().max().item() < 1e-4
 
 
-@pytest.mark.parametrize("cfg", [(1, 2, 5), (4, 64, 1024), (16, 64, 2048), (3, 37, 70)])
+@pytest.mark.parametrize("cfg", [(1, 2, 5), (4, 64, 1024), (16, 64, 2048), (3, 37, 70), (2, 100, 70), (2, 200, 70)])
 def test_bn_train_forward_backward(cfg):
     L, st = _L()
     ns, M, N = cfg

@@ -15,19 +15,47 @@
 
 namespace {
 
-// Sum of the split-K slabs of one element, in a fixed order (4 independent partial sums keep 4 loads in flight).
+// Sum of the split-K slabs of one element.  Every slab load is issued before the first add (the loads are
+// independent; a loop that waits for each one pays the L2/HBM latency ns times), slabs beyond ns re-read slab 0 and
+// are discarded.  The sum is a fixed pairwise tree over 16 slots with zeros in the unused ones, so the result does
+// not depend on which NS instantiation ran: ((v0+v1)+(v2+v3)) + ((v4+v5)+(v6+v7)) + ...
+template <int NS>
+__device__ __forceinline__ float slab_tree(const float* __restrict__ p, int ns, long ss) {
+    float v[NS];
+#pragma unroll
+    for (int z = 0; z < NS; ++z) v[z] = p[(z < ns ? (long)z : 0l) * ss];
+#pragma unroll
+    for (int z = 0; z < NS; ++z) v[z] = z < ns ? v[z] : 0.f;
+#pragma unroll
+    for (int w = 1; w < NS; w *= 2)
+#pragma unroll
+        for (int z = 0; z + w < NS; z += 2 * w) v[z] += v[z + w];
+    return v[0];
+}
 __device__ __forceinline__ float slab_sum(const float* __restrict__ P, int ns, long ss, long idx) {
     const float* p = P + idx;
-    float a0 = p[0], a1 = 0.f, a2 = 0.f, a3 = 0.f;
-    int z = 1;
-    for (; z + 3 < ns; z += 4) {
-        a1 += p[(long)z * ss];
-        a2 += p[(long)(z + 1) * ss];
-        a3 += p[(long)(z + 2) * ss];
-        a0 += p[(long)(z + 3) * ss];
-    }
-    for (; z < ns; ++z) a1 += p[(long)z * ss];
-    return (a0 + a1) + (a2 + a3);
+    if (ns <= 2) return slab_tree<2>(p, ns, ss);
+    if (ns <= 4) return slab_tree<4>(p, ns, ss);
+    if (ns <= 8) return slab_tree<8>(p, ns, ss);
+    float a = slab_tree<16>(p, ns, ss);
+    for (int z = 16; z < ns; ++z) a += p[(long)z * ss];
+    return a;
+}
+template <int NS>
+__device__ __forceinline__ float4 slab_tree4(const float* __restrict__ p, int ns, long ss) {
+    float4 v[NS];
+#pragma unroll
+    for (int z = 0; z < NS; ++z) v[z] = *reinterpret_cast<const float4*>(p + (z < ns ? (long)z : 0l) * ss);
+#pragma unroll
+    for (int z = 0; z < NS; ++z)
+        if (z >= ns) v[z] = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+    for (int w = 1; w < NS; w *= 2)
+#pragma unroll
+        for (int z = 0; z + w < NS; z += 2 * w) {
+            v[z].x += v[z + w].x; v[z].y += v[z + w].y; v[z].z += v[z + w].z; v[z].w += v[z + w].w;
+        }
+    return v[0];
 }
 
 __device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + __expf(-x)); }
@@ -39,20 +67,17 @@ template <bool VEC>
 __device__ __forceinline__ float4 slab_sum4(const float* __restrict__ P, int ns, long ss, long idx, int nvalid) {
     float4 a;
     if constexpr (VEC) {
-        a = *reinterpret_cast<const float4*>(P + idx);
-        float4 c = make_float4(0.f, 0.f, 0.f, 0.f);
-        int z = 1;
-        for (; z + 1 < ns; z += 2) {
-            const float4 b0 = *reinterpret_cast<const float4*>(P + (long)z * ss + idx);
-            const float4 b1 = *reinterpret_cast<const float4*>(P + (long)(z + 1) * ss + idx);
-            a.x += b0.x; a.y += b0.y; a.z += b0.z; a.w += b0.w;
-            c.x += b1.x; c.y += b1.y; c.z += b1.z; c.w += b1.w;
+        const float* p = P + idx;
+        if (ns <= 2) a = slab_tree4<2>(p, ns, ss);
+        else if (ns <= 4) a = slab_tree4<4>(p, ns, ss);
+        else if (ns <= 8) a = slab_tree4<8>(p, ns, ss);
+        else {
+            a = slab_tree4<16>(p, ns, ss);
+            for (int z = 16; z < ns; ++z) {
+                const float4 b0 = *reinterpret_cast<const float4*>(p + (long)z * ss);
+                a.x += b0.x; a.y += b0.y; a.z += b0.z; a.w += b0.w;
+            }
         }
-        if (z < ns) {
-            const float4 b0 = *reinterpret_cast<const float4*>(P + (long)z * ss + idx);
-            a.x += b0.x; a.y += b0.y; a.z += b0.z; a.w += b0.w;
-        }
-        a.x += c.x; a.y += c.y; a.z += c.z; a.w += c.w;
     } else {
         float t[4] = {0.f, 0.f, 0.f, 0.f};
         for (int k = 0; k < nvalid; ++k) t[k] = slab_sum(P, ns, ss, idx + k);
@@ -387,6 +412,76 @@ __global__ void bn_train_relu_kernel(const float* __restrict__ P, int ns, long s
     }
 }
 
+// Small-batch form of bn_train_relu (M <= RG * RPT rows): each thread keeps its rows of the column in registers
+// instead of parking them in memory between the three passes, and the block is CTS columns wide so that a
+// 1024-column layer spreads over N / CTS workgroups.  Same summation order as the kernels above (bit-identical).
+template <int CTS>
+__device__ __forceinline__ float rg_reduce_t(float v, float (*red)[CTS]) {
+    __syncthreads();
+    red[threadIdx.y][threadIdx.x] = v;
+    __syncthreads();
+    float r = 0.f;
+#pragma unroll
+    for (int g = 0; g < RG; ++g) r += red[g][threadIdx.x];
+    return r;
+}
+
+template <int CTS, int RPT>
+__global__ __launch_bounds__(CTS * RG) void bn_train_relu_small_kernel(
+    const float* __restrict__ P, int ns, long ss, int ldp, int M, int N, const float* __restrict__ bias, float eps,
+    const float* __restrict__ gamma, const float* __restrict__ beta, float* __restrict__ XH, float* __restrict__ H,
+    int ldo, float* __restrict__ mean, float* __restrict__ m2, float* __restrict__ invstd_out,
+    float* __restrict__ rmean, float* __restrict__ rvar, float momentum, int nupd) {
+    __shared__ float red[RG][CTS];
+    const int n = blockIdx.x * CTS + threadIdx.x, rg = threadIdx.y;
+    const bool ok = n < N;
+    const float b = ok && bias ? bias[n] : 0.f;
+    float z[RPT];
+    float s = 0.f;
+#pragma unroll
+    for (int r = 0; r < RPT; ++r) {
+        const int m = rg + RG * r;
+        z[r] = 0.f;
+        if (ok && m < M) {
+            z[r] = slab_sum(P, ns, ss, (long)m * ldp + n) + b;
+            s += z[r];
+        }
+    }
+    const float mu = rg_reduce_t<CTS>(s, red) / (float)M;
+    float q = 0.f;
+#pragma unroll
+    for (int r = 0; r < RPT; ++r)
+        if (ok && rg + RG * r < M) {
+            const float d = z[r] - mu;
+            q = __fmaf_rn(d, d, q);
+        }
+    q = rg_reduce_t<CTS>(q, red);
+    if (!ok) return;
+    const float istd = 1.0f / sqrtf(q / (float)M + eps);
+    const float ga = gamma[n], be = beta[n];
+#pragma unroll
+    for (int r = 0; r < RPT; ++r) {
+        const int m = rg + RG * r;
+        if (m < M) {
+            const float xh = (z[r] - mu) * istd;
+            XH[(long)m * ldo + n] = xh;
+            H[(long)m * ldo + n] = fmaxf(__fmaf_rn(xh, ga, be), 0.f);
+        }
+    }
+    if (rg == 0) {
+        mean[n] = mu; m2[n] = q; invstd_out[n] = istd;
+        if (rmean) {
+            const float uv = q / ((float)M - 1.f);
+            float rm = rmean[n], rv = rvar[n];
+            for (int u = 0; u < nupd; ++u) {
+                rm = (1.f - momentum) * rm + momentum * mu;
+                rv = (1.f - momentum) * rv + momentum * uv;
+            }
+            rmean[n] = rm; rvar[n] = rv;
+        }
+    }
+}
+
 // apply: var = m2 / count (biased); xhat = (z - mean) * rsqrt(var + eps); h = relu(gamma * xhat + beta).
 // running stats: rm = (1-mom) rm + mom mean; rv = (1-mom) rv + mom * m2 / (count - 1), applied nupd times
 // (the G-step re-runs the same forward on the same batch: src/mlp_df_wgan_train.py:196,240).
@@ -479,6 +574,49 @@ __global__ void bn_bwd_kernel(const float* __restrict__ P, int ns, long ss, int 
         sb = rg_reduce(sb, red);
         if (ok && rg == 0) { dgamma[n] = s1; dbeta[n] = s0; dbias[n] = sb; }
     }
+}
+
+// Small-batch single-launch form of bn_bwd (phase 3 only): dy and xhat stay in registers.  Same summation order.
+template <int CTS, int RPT>
+__global__ __launch_bounds__(CTS * RG) void bn_bwd_small_kernel(
+    const float* __restrict__ P, int ns, long ss, int ldp, int M, int N, const float* __restrict__ H,
+    const float* __restrict__ XH, int ldh, const float* __restrict__ gamma, const float* __restrict__ invstd,
+    float count, float* __restrict__ sums, float* __restrict__ DZ, int lddz, float* __restrict__ dgamma,
+    float* __restrict__ dbeta, float* __restrict__ dbias) {
+    __shared__ float red[RG][CTS];
+    const int n = blockIdx.x * CTS + threadIdx.x, rg = threadIdx.y;
+    const bool ok = n < N;
+    float dy[RPT], xh[RPT];
+    float s0 = 0.f, s1 = 0.f;
+#pragma unroll
+    for (int r = 0; r < RPT; ++r) {
+        const int m = rg + RG * r;
+        dy[r] = 0.f; xh[r] = 0.f;
+        if (ok && m < M) {
+            const long o = (long)m * ldh + n;
+            dy[r] = H[o] > 0.f ? slab_sum(P, ns, ss, (long)m * ldp + n) : 0.f;
+            xh[r] = XH[o];
+            s0 += dy[r];
+            s1 = __fmaf_rn(dy[r], xh[r], s1);
+        }
+    }
+    s0 = rg_reduce_t<CTS>(s0, red);
+    s1 = rg_reduce_t<CTS>(s1, red);
+    float sb = 0.f;
+    if (ok) {
+        const float k = gamma[n] * invstd[n], a0 = s0 / count, a1 = s1 / count;
+#pragma unroll
+        for (int r = 0; r < RPT; ++r) {
+            const int m = rg + RG * r;
+            if (m < M) {
+                const float dz = k * (dy[r] - a0 - xh[r] * a1);
+                DZ[(long)m * lddz + n] = dz;
+                sb += dz;
+            }
+        }
+    }
+    sb = rg_reduce_t<CTS>(sb, red);
+    if (ok && rg == 0) { sums[n] = s0; sums[N + n] = s1; dgamma[n] = s1; dbeta[n] = s0; dbias[n] = sb; }
 }
 
 // Generator output: y = sigmoid(sumP + b); bl = y0 * (smax - smin) + smin (two fp32 roundings, as torch does);
@@ -678,6 +816,19 @@ int wfd_bn_train_relu(const float* P, int ns, long ss, int ldp, int M, int N, co
                       const float* gamma, const float* beta, float* XH, float* H, int ldo, float* mean, float* m2,
                       float* invstd, float* rmean, float* rvar, float momentum, int nupd, void* stream) {
     if (!P || !gamma || !beta || !XH || !H || !mean || !m2 || !invstd || M < 2) return WFD_ERR_ARG;
+    if (M <= RG * 8) {
+        constexpr int CTS = 8;
+        if (M <= RG * 4)
+            hipLaunchKernelGGL((bn_train_relu_small_kernel<CTS, 4>), dim3(cdiv(N, CTS)), dim3(CTS, RG), 0,
+                               (hipStream_t)stream, P, ns, ss, ldp, M, N, bias, eps, gamma, beta, XH, H, ldo, mean, m2,
+                               invstd, rmean, rvar, momentum, nupd);
+        else
+            hipLaunchKernelGGL((bn_train_relu_small_kernel<CTS, 8>), dim3(cdiv(N, CTS)), dim3(CTS, RG), 0,
+                               (hipStream_t)stream, P, ns, ss, ldp, M, N, bias, eps, gamma, beta, XH, H, ldo, mean, m2,
+                               invstd, rmean, rvar, momentum, nupd);
+        WFD_CHECK_LAUNCH();
+        return WFD_OK;
+    }
     hipLaunchKernelGGL(bn_train_relu_kernel, dim3(cdiv(N, CT)), dim3(CT, RG), 0, (hipStream_t)stream, P, ns, ss, ldp, M,
                        N, bias, eps, gamma, beta, XH, H, ldo, mean, m2, invstd, rmean, rvar, momentum, nupd);
     WFD_CHECK_LAUNCH();
@@ -708,6 +859,17 @@ int wfd_bn_bwd(const float* P, int ns, long ss, int ldp, int M, int N, const flo
                float* dbeta, float* dbias, int phase, void* stream) {
     if (!P || !H || !XH || !gamma || !invstd || !sums) return WFD_ERR_ARG;
     if (!DZ || ((phase & 2) && (!dgamma || !dbeta || !dbias))) return WFD_ERR_ARG;
+    if (phase == 3 && M <= RG * 8) {
+        constexpr int CTS = 8;
+        if (M <= RG * 4)
+            hipLaunchKernelGGL((bn_bwd_small_kernel<CTS, 4>), dim3(cdiv(N, CTS)), dim3(CTS, RG), 0, (hipStream_t)stream, P,
+                               ns, ss, ldp, M, N, H, XH, ldh, gamma, invstd, count, sums, DZ, lddz, dgamma, dbeta, dbias);
+        else
+            hipLaunchKernelGGL((bn_bwd_small_kernel<CTS, 8>), dim3(cdiv(N, CTS)), dim3(CTS, RG), 0, (hipStream_t)stream, P,
+                               ns, ss, ldp, M, N, H, XH, ldh, gamma, invstd, count, sums, DZ, lddz, dgamma, dbeta, dbias);
+        WFD_CHECK_LAUNCH();
+        return WFD_OK;
+    }
     hipLaunchKernelGGL(bn_bwd_kernel, dim3(cdiv(N, CT)), dim3(CT, RG), 0, (hipStream_t)stream, P, ns, ss, ldp, M, N, H, XH,
                        ldh, gamma, invstd, count, sums, DZ, lddz, dgamma, dbeta, dbias, phase);
     WFD_CHECK_LAUNCH();

@@ -46,21 +46,33 @@ DF_CONVS = [  # (conv prefix, bn prefix, Cin, Cout, act, pool_after) -- src/mode
 
 class FlatParams:
     """Parameters of one network in ONE flat fp32 buffer (tensor offsets 16-byte aligned) with matching flat
-    gradient and RMSprop square-average buffers: the optimizer and the gradient all-reduce are one pass each."""
+    gradient and RMSprop square-average buffers: the optimizer and the gradient all-reduce are one pass each.
+    Weight matrices are stored with their row stride ``ld[name]`` rounded up to 4 floats, so that every row starts
+    16-byte aligned and the GEMM kernels can stage them with 128-bit loads (the critic's first layer has 1501
+    columns).  The pad columns stay zero: their gradient is never written, and RMSprop maps (p=0, g=0, sq=0) to 0.
+    ``p[name]`` / ``g[name]`` are views of the logical shape."""
 
     def __init__(self, specs, device):
         self.specs = specs
         self.offsets: Dict[str, int] = {}
+        self.ld: Dict[str, int] = {}
         off = 0
         for name, shape in specs:
             self.offsets[name] = off
-            off += rup(math.prod(shape), 4)
+            self.ld[name] = rup(shape[-1], 4) if len(shape) == 2 else shape[-1]
+            off += rup(math.prod(shape[:-1]) * self.ld[name], 4)
         self.numel = off
         self.flat = torch.zeros(off, dtype=torch.float32, device=device)
         self.grad = torch.zeros(off, dtype=torch.float32, device=device)
         self.sq = torch.zeros(off, dtype=torch.float32, device=device)
-        self.p = {n: self.flat[self.offsets[n]: self.offsets[n] + math.prod(s)].view(s) for n, s in specs}
-        self.g = {n: self.grad[self.offsets[n]: self.offsets[n] + math.prod(s)].view(s) for n, s in specs}
+        self.p = {n: self._view(self.flat, n, s) for n, s in specs}
+        self.g = {n: self._view(self.grad, n, s) for n, s in specs}
+
+    def _view(self, flat: torch.Tensor, name: str, shape):
+        o, ld = self.offsets[name], self.ld[name]
+        if len(shape) == 2:
+            return flat[o: o + shape[0] * ld].view(shape[0], ld)[:, : shape[1]]
+        return flat[o: o + shape[0]]
 
     def load(self, sd: Dict[str, torch.Tensor]):
         for n, s in self.specs:
@@ -70,7 +82,7 @@ class FlatParams:
             self.p[n].copy_(t.detach().to(torch.float32))
 
     def state(self) -> Dict[str, torch.Tensor]:
-        return {n: self.p[n].detach().clone() for n, _ in self.specs}
+        return {n: self.p[n].detach().clone(memory_format=torch.contiguous_format) for n, _ in self.specs}
 
 
 def fold_bn(sd, bn: str, lin_bias: torch.Tensor, eps: float = 1e-5):
@@ -317,7 +329,7 @@ class TrainEngine:
     def _g_forward(self, p: Plan, nupd: int):
         """Generator.forward in training mode (src/model.py:36-48) -> fake rows of the critic input."""
         B, S, C, Z, b, G = self.B, self.S, self.C, self.Z, self.buf, self.Gp.p
-        s = p.gemm(NT, b["ZIN"], self.ldz, G["model.0.weight"], Z + C, B, 512, Z + C)
+        s = p.gemm(NT, b["ZIN"], self.ldz, G["model.0.weight"], self.Gp.ld["model.0.weight"], B, 512, Z + C)
         p.affine_act(s, None, G["model.0.bias"], ACT_RELU, b["GH1"], 512)
         prev, kprev = b["GH1"], 512
         for i, lin, bn, n in ((2, "model.2", "model.3", 1024), (3, "model.5", "model.6", 2048)):
@@ -359,7 +371,7 @@ class TrainEngine:
     def _critic_forward(self, p: Plan, X, M: int, mk, H1, H2, H3, D1, D2, D3, V, DL3, DL3s, rowscale):
         """Discriminator.forward (src/model.py:69-72) on M rows of X, keeping d_i; ends with the head + delta_3."""
         S, C, D = self.S, self.C, self.Dp.p
-        s = p.gemm(NT, X, self.ldx, D["model.0.weight"], S + C, M, 2048, S + C)
+        s = p.gemm(NT, X, self.ldx, D["model.0.weight"], self.Dp.ld["model.0.weight"], M, 2048, S + C)
         p.lrelu_drop(s, D["model.0.bias"], mk[0], 2048, H1, 2048, D1, 2048)
         s = p.gemm(NT, H1, 2048, D["model.3.weight"], 2048, M, 1024, 2048)
         p.lrelu_drop(s, D["model.3.bias"], mk[1], 1024, H2, 1024, D2, 1024)
@@ -375,7 +387,7 @@ class TrainEngine:
         p.mul(s, D2, 1024, DM_MUL, None, rowscale, DL2, DL2s, 1024)
         s = p.gemm(NN, DL2, 1024, D["model.3.weight"], 2048, M, 2048, 1024)
         p.mul(s, D1, 2048, DM_MUL, None, rowscale, DL1, DL1s, 2048)
-        return p.gemm(NN, DL1, 2048, D["model.0.weight"], S + C, M, S, 2048)
+        return p.gemm(NN, DL1, 2048, D["model.0.weight"], self.Dp.ld["model.0.weight"], M, S, 2048)
 
     GOLD = 0x9E3779B97F4A7C15
 
@@ -416,9 +428,10 @@ class TrainEngine:
         Dp = D.p
         p.fork()
         with p.side():
-            p.gemm(TN, b["DL1"], 2048, b["XC"], self.ldx, 2048, S + C, 2 * M, out=D.g["model.0.weight"], ldp=S + C)
+            p.gemm(TN, b["DL1"], 2048, b["XC"], self.ldx, 2048, S + C, 2 * M, out=D.g["model.0.weight"],
+                   ldp=D.ld["model.0.weight"])
         self._grad_bucket_hook(p, "D", first=True)
-        s = p.gemm(NT, b["XC"], self.ldx, Dp["model.0.weight"], S + C, M, 2048, S)
+        s = p.gemm(NT, b["XC"], self.ldx, Dp["model.0.weight"], D.ld["model.0.weight"], M, 2048, S)
         p.mul(s, b["D1"], 2048, DM_MUL, None, None, b["T1H1"][:M], None, 2048)
         p.fork()
         with p.side():
@@ -474,7 +487,7 @@ class TrainEngine:
         fp = self.Dp if which == "D" else self.Gp
         key = "model.0.weight" if which == "D" else "model.8.weight"
         lo = fp.offsets[key]
-        hi = lo + fp.p[key].numel() if which == "D" else fp.numel
+        hi = lo + fp.p[key].shape[0] * fp.ld[key] if which == "D" else fp.numel
         big = fp.grad[lo:hi]
         rest = fp.grad[hi:] if which == "D" else fp.grad[:lo]
         gs = self._gsync
@@ -575,7 +588,8 @@ class TrainEngine:
         s = p.gemm(NN, prev_dz, 1024, Gp["model.2.weight"], 512, B, 512, 1024)
         p.mul(s, b["GH1"], 512, DM_RELU, None, None, b["GDZ1"], None, 512)
         p.add(self.L.colsum, ptr(b["GDZ1"]), 512, B, 512, 0, ptr(G.g["model.0.bias"]), 0)
-        p.gemm(TN, b["GDZ1"], 512, b["ZIN"], self.ldz, 512, Z + C, B, out=G.g["model.0.weight"], ldp=Z + C)
+        p.gemm(TN, b["GDZ1"], 512, b["ZIN"], self.ldz, 512, Z + C, B, out=G.g["model.0.weight"],
+               ldp=G.ld["model.0.weight"])
         p.join()
         self._grad_sync_hook(p, "G")
         p.add(self.L.rmsprop, ptr(G.flat), ptr(G.grad), ptr(G.sq), G.numel, self.lr, 0.99, 1e-8, self.gscale,
@@ -700,7 +714,7 @@ class TrainEngine:
     def generator_state(self) -> Dict[str, torch.Tensor]:
         sd = {}
         for key in ("model.0", "model.2", "model.3", "model.5", "model.6", "model.8"):
-            sd[f"{key}.weight"] = self.Gp.p[f"{key}.weight"].detach().clone()
+            sd[f"{key}.weight"] = self.Gp.p[f"{key}.weight"].detach().clone(memory_format=torch.contiguous_format)
             sd[f"{key}.bias"] = self.Gp.p[f"{key}.bias"].detach().clone()
             if key in ("model.3", "model.6"):
                 sd[f"{key}.running_mean"] = self.Gbuf[f"{key}.running_mean"].clone()
