@@ -244,6 +244,25 @@ __global__ void ep_penalty_row_kernel(const float* __restrict__ P, int ns, long 
 // reduce over the row groups) so that a 64..128-row batch still spreads over N/32 workgroups.
 constexpr int CT = 32, RG = 16;
 
+// sum over this thread's rows m = m0, m0 + RG, ... of X[m][n] * rs[m], eight independent loads in flight per batch
+// (same add order as the plain loop)
+__device__ __forceinline__ float col_partial(const float* __restrict__ X, int ldx, const float* __restrict__ rs, int M,
+                                             int n, int m0, float a) {
+    int m = m0;
+    for (; m + 7 * RG < M; m += 8 * RG) {
+        float x[8], r[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            x[k] = X[(long)(m + k * RG) * ldx + n];
+            r[k] = rs ? rs[m + k * RG] : 1.f;
+        }
+#pragma unroll
+        for (int k = 0; k < 8; ++k) a += x[k] * r[k];
+    }
+    for (; m < M; m += RG) a += X[(long)m * ldx + n] * (rs ? rs[m] : 1.f);
+    return a;
+}
+
 __device__ __forceinline__ float rg_reduce(float v, float (*red)[CT]) {
     __syncthreads();
     red[threadIdx.y][threadIdx.x] = v;
@@ -260,8 +279,7 @@ __global__ void colsum_kernel(const float* __restrict__ X, int ldx, int M, int N
     __shared__ float red[RG][CT];
     const int n = blockIdx.x * CT + threadIdx.x;
     float a = 0.f;
-    if (n < N)
-        for (int m = threadIdx.y; m < M; m += RG) a += X[(long)m * ldx + n] * (rowscale ? rowscale[m] : 1.f);
+    if (n < N) a = col_partial(X, ldx, rowscale, M, n, threadIdx.y, a);
     a = rg_reduce(a, red);
     if (n < N && threadIdx.y == 0) out[n] = accumulate ? out[n] + a : a;
 }
@@ -286,11 +304,10 @@ __global__ void colsum_multi_kernel(const long long* __restrict__ desc, int nseg
     float* acc = reinterpret_cast<float*>(d[10]);
     const int n = ((int)blockIdx.x - (int)d[9]) * CT + threadIdx.x;
     float a = 0.f;
-    if (n < N)
-        for (int m = threadIdx.y; m < M; m += RG) {
-            a += X[(long)m * ldx + n] * (rs ? rs[m] : 1.f);
-            if (X2) a += X2[(long)m * ldx2 + n] * (rs2 ? rs2[m] : 1.f);
-        }
+    if (n < N) {
+        a = col_partial(X, ldx, rs, M, n, threadIdx.y, a);
+        if (X2) a += col_partial(X2, ldx2, rs2, M, n, threadIdx.y, 0.f);
+    }
     a = rg_reduce(a, red);
     if (n < N && threadIdx.y == 0) {
         out[n] = a;
@@ -653,16 +670,28 @@ __global__ void g_out_bwd_kernel(const float* __restrict__ P, int ns, long ss, i
     const int j = blockIdx.x * CT + threadIdx.x;
     float sb = 0.f;
     if (j < S)
-        for (int m = threadIdx.y; m < M; m += RG) {
-            float dz = 0.f;
-            if (j < idx[m]) {
-                float df = dscale * slab_sum(P, ns, ss, (long)m * ldp + j);
-                if (dDF && j >= 1) df += dDF[(long)m * lddf + j - 1];
-                const float y = fake[(long)m * ldf + j];
-                dz = df * y * (1.f - y);
+        for (int m0 = threadIdx.y; m0 < M; m0 += 4 * RG) {
+            // four rows per batch, every load issued before the arithmetic (rows past M re-read row m0)
+            float g[4], dd[4], y[4];
+            int lim[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const int m = m0 + k * RG < M ? m0 + k * RG : m0;
+                g[k] = slab_sum(P, ns, ss, (long)m * ldp + j);
+                dd[k] = (dDF && j >= 1) ? dDF[(long)m * lddf + j - 1] : 0.f;
+                y[k] = fake[(long)m * ldf + j];
+                lim[k] = idx[m];
             }
-            DZ[(long)m * lddz + j] = dz;
-            sb += dz;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const int m = m0 + k * RG;
+                if (m < M) {
+                    float dz = 0.f;
+                    if (j < lim[k]) dz = (dscale * g[k] + dd[k]) * y[k] * (1.f - y[k]);
+                    DZ[(long)m * lddz + j] = dz;
+                    sb += dz;
+                }
+            }
         }
     sb = rg_reduce(sb, red);
     if (j < S && threadIdx.y == 0) dbias[j] = sb;
