@@ -76,44 +76,60 @@ def run_steps(eng, start, n):
         eng.iteration(i)          # re-permutes by itself at epoch ends
 
 
-def gemm_roofline(eng, n_iters=6):
-    """Instrumented eager pass: HIP events (torch.cuda.Event on the launch stream) around every GEMM-core launch of
-    the same fast-mode plans; returns achieved TFLOP/s = sum(flops) / sum(duration) and the per-launch averages."""
-    from wfd_gan_amd.plan import HOST
+def gemm_roofline(eng, rep=16, rounds=3):
+    """Live timing of the dominant kernel (the fp32 MFMA GEMM core, all its layouts) at the launches of one group of
+    three iterations (3 D-steps + 1 G-step).  Every GEMM launch of the fast-mode plans is captured `rep` times
+    back-to-back in a HIP graph of its own and the replay is bracketed by HIP events on the launch stream
+    (torch.cuda.Event on the current stream); a launch only writes its slabs / output, so repeating it changes no
+    state.  Per-launch time = replay time / rep, which amortises the event pair and the graph launch and keeps the
+    host out of the measurement.  achieved = sum(flops) / sum(time) over the launches of the group, weighted as they
+    occur (D-step launches x3)."""
+    from wfd_gan_amd.plan import FORK, HOST, JOIN
     L = eng.L
     gemm_fns = {L.gemm_f32: "gemm", L.conv8_gemm_f32: "conv", L.gemm_f32_fused: "gemm_fused",
                 L.conv8_gemm_f32_fused: "conv"}
-    from wfd_gan_amd.plan import FORK, JOIN
-    stream = torch.cuda.current_stream().cuda_stream
-    recs = []
-    for it in range(n_iters):
-        plans = [eng.fast_d] + ([eng.fast_g] if it % eng.n_critic == 0 else [])
-        for plan in plans:
-            for fn, a, _lane in plan.calls:       # everything on ONE stream here: each launch is timed alone
-                if fn is FORK or fn is JOIN:
-                    continue
-                if fn is HOST:
-                    a[0]()
-                    continue
-                kind = gemm_fns.get(fn)
-                if kind is None:
-                    fn(*a, stream)
-                    continue
-                if kind == "gemm":
-                    M, N, K = a[8], a[9], a[10]
-                elif kind == "gemm_fused":
-                    M, N, K = a[7], a[8], a[9]
-                else:
-                    M, N, K = a[1] * a[2], a[6], 8 * a[3]
-                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-                e0.record()
-                fn(*a, stream)
-                e1.record()
-                recs.append((2.0 * M * N * K, e0, e1))
+    calls = []
+    for plan, weight in ((eng.fast_d, eng.n_critic), (eng.fast_g, 1)):
+        for fn, a, _lane in plan.calls:
+            if fn is FORK or fn is JOIN or fn is HOST:
+                continue
+            kind = gemm_fns.get(fn)
+            if kind is None:
+                continue
+            if kind == "gemm":
+                M, N, K = a[8], a[9], a[10]
+            elif kind == "gemm_fused":
+                M, N, K = a[7], a[8], a[9]
+            else:
+                M, N, K = a[1] * a[2], a[6], 8 * a[3]
+            calls.append((fn, a, 2.0 * M * N * K, weight))
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):                      # load every kernel variant before capturing
+        for fn, a, _, _ in calls:
+            fn(*a, side.cuda_stream)
+    torch.cuda.current_stream().wait_stream(side)
     torch.cuda.synchronize()
-    flops = sum(r[0] for r in recs)
-    ms = sum(r[1].elapsed_time(r[2]) for r in recs)
-    n = len(recs)
+    flops = ms = 0.0
+    n = 0
+    for fn, a, fl, weight in calls:
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g):
+            st = torch.cuda.current_stream().cuda_stream
+            for _ in range(rep):
+                fn(*a, st)
+        g.replay()
+        tot = 0.0
+        for _ in range(rounds):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            g.replay()
+            e1.record()
+            e1.synchronize()
+            tot += e0.elapsed_time(e1) / rep
+        flops += fl * weight
+        ms += tot / rounds * weight
+        n += weight
     return dict(launches=n, avg_flops=flops / n, avg_us=ms * 1e3 / n, tflops=flops / (ms * 1e-3) / 1e12)
 
 
