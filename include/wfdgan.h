@@ -227,6 +227,43 @@ int wfd_sample_post(const float* Y, int ldy, int M, int S, const double* min_, c
 int wfd_sample_post_mode(const float* Y, int ldy, int M, int S, const double* min_, const double* scale_, int mode, int* out,
                          int ldo, int* len_out, void* stream);
 
+/* ---- DF observer training (src/train_df.py:111-131 around src/model.py:135-206 in train mode) ---------------------- */
+
+/* weight gradient of the k=8 "SAME" conv (autograd of MyConv1dPadSame, src/model.py:91-104):
+ * P[co][t*Cin+ci] = sum_{b,l} dY[b*L+l][co] * X[b][l+t-3][ci]; `splits` slabs of Cout x ldp floats */
+int wfd_conv8_wgrad_f32(const float* dY, const float* X, int Bn, int L, int Cin, int Cout, float* P, int ldp,
+                        long slab_stride, int splits, void* stream);
+
+/* nn.BatchNorm1d on a channels-last conv activation Z[M = B*L][N] in training mode (src/model.py:142,146,...):
+ * statistics over all M rows (two-stage, deterministic), running stats with the unbiased variance.
+ * part: scratch of ceil(M / rows_per_chunk) * 2 * N floats */
+int wfd_bn_tall_stats(const float* Z, int ldz, int M, int N, int rows_per_chunk, float* part, float eps, float momentum,
+                      float* mean, float* invstd, float* rmean, float* rvar, void* stream);
+/* Y = act(gamma * (Z - mean) * invstd + beta); act 0 none, 1 ReLU, 2 ELU */
+int wfd_bn_tall_apply(const float* Z, int M, int N, const float* mean, const float* invstd, const float* gamma,
+                      const float* beta, int act, float* Y, void* stream);
+/* backward of that BatchNorm given dA = d loss / d (BN output): sums = [sum dA ; sum dA*xhat], dgamma, dbeta,
+ * dZ = gamma * invstd * (dA - s0/M - xhat * s1/M)   (dZ may alias dA) */
+int wfd_bn_tall_bwd(const float* dA, const float* Z, int M, int N, int rows_per_chunk, float* part, const float* mean,
+                    const float* invstd, const float* gamma, float* sums, float* dgamma, float* dbeta, float* dZ,
+                    void* stream);
+/* out[n] = sum_m X[m][n] over a tall matrix (conv bias gradients); part: ceil(M / rows_per_chunk) * N floats */
+int wfd_colsum_tall(const float* X, int ld, int M, int N, int rows_per_chunk, float* part, float* out, void* stream);
+/* weight gradient of the first conv (Cin = 1): dW[co][t] = sum_{b,l} dZ[b][l][co] * x[b][l+t-3], x[b][l] = X[b*ldx+xoff+l];
+ * part: ceil(L / 256) * Bn * Cout * 8 floats */
+int wfd_conv1_wgrad(const float* dZ, const float* X, int ldx, int xoff, int Bn, int L, int Cout, float* part, float* dW,
+                    void* stream);
+/* WT[ci][t'*Cout+co] = W[co][(7-t')*Cin+ci]: the operand of the input-gradient conv, rebuilt after every update */
+int wfd_conv_wflip(const float* W, int Cout, int Cin, float* WT, void* stream);
+/* nn.Dropout as a mask multiply (mask values {0, 1/(1-p)} from wfd_rng_dropout_mask); out may alias X */
+int wfd_mul_mask(const float* X, const float* mask, long n, float* out, void* stream);
+/* torch.optim.Adamax step with torch's defaults passed in (src/train_df.py:115); step[0] = steps taken so far, kept on
+ * the device and incremented when advance != 0 */
+int wfd_adamax(float* p, const float* g, float* m, float* u, long n, float lr, float beta1, float beta2, float eps,
+               long long* step, int advance, void* stream);
+/* correct[0] += #{rows whose first-maximum logit index equals the label} (src/train_df.py:141-143,153-155) */
+int wfd_argmax_correct(const float* logits, int ldl, int M, int C, const int* labels, int* correct, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -20,7 +20,9 @@ What it does
   6. PIN E: the reference's utils.compute_gradient_penalty (WGAN-GP, src/utils.py:64-84) == oracle.wgan_gp_penalty,
   7. PIN F: the other consumers' integer epilogues (gan_wt.py:79-87, gan_glue.py:114-124, synthesize.py:86-90), run
      by the reference's own functions == oracle.POSTPROCESS[...],
-  8. writes the fixtures (inputs, masks as packed bits, expected outputs).  Weights are NOT stored: tests
+  8. PIN G: the reference DF module in train mode + torch.optim.Adamax (src/train_df.py:113-131) ==
+     oracle.df_train.DFTrainer (loss, logits, every gradient, every parameter / BN buffer after the step),
+  9. writes the fixtures (inputs, masks as packed bits, expected outputs).  Weights are NOT stored: tests
      re-derive them from the seed with oracle.make_state and check the stored checksums.
 """
 import argparse
@@ -446,6 +448,72 @@ def make_postprocess_modes(ref_model):
 
 
 # ------------------------------------------------------------------------------------------------
+def make_df_train_case(ref_model, name, length, class_dim, batch, n_steps, seed):
+    """PIN G + fixture: the reference DF module in train mode + torch.optim.Adamax (src/train_df.py:113-131) vs
+    oracle.df_train.DFTrainer, bit-exact; dropout masks recovered by RNG replay and stored as packed bits."""
+    from oracle import df_train as DT
+    print(f"[df_train {name}] L={length} C={class_dim} B={batch}")
+    torch.manual_seed(seed)
+    model = ref_model.DF(length, class_dim)
+    sd0 = {k: v.detach().clone() for k, v in model.state_dict().items()}
+    opt = torch.optim.Adamax(model.parameters())
+    crit = torch.nn.CrossEntropyLoss()
+    tr = DT.DFTrainer(sd0)
+    tr2 = DT.DFTrainer(sd0)                                            # explicit-mask path
+    g = torch.Generator().manual_seed(seed + 1)
+    fx = dict(meta=json.dumps(dict(length=length, class_dim=class_dim, batch=batch, n_steps=n_steps, seed=seed)),
+              init_checksum=checksum(sd0))
+    keys = DT.df_param_keys(sd0)
+    shapes = DT.dropout_mask_shapes(length, batch)
+    for it in range(n_steps):
+        x = torch.rand(batch, 1, length, generator=g)
+        x = x * (torch.arange(length) < torch.randint(length // 4, length, (batch, 1, 1), generator=g)).float()
+        y = torch.randint(0, class_dim, (batch,), generator=g)
+        model.train()
+        torch.manual_seed(1000 + it)
+        out = model(x)
+        loss = crit(out, y)
+        opt.zero_grad()
+        loss.backward()
+        grads_ref = {k: p.grad.detach().clone() for k, p in zip(keys, model.parameters())}
+        opt.step()
+        # oracle, dropout drawn the same way
+        torch.manual_seed(1000 + it)
+        r = tr.step(x, y, keep=True)
+        assert float(loss) == r["loss"], (it, float(loss), r["loss"])
+        assert_same(out.detach(), r["logits"], f"df_train logits it{it}")
+        for k in keys:
+            assert_same(grads_ref[k], r["grads"][k], f"df_train grad {k} it{it}")
+        for k, v in model.state_dict().items():
+            assert_same(v, tr.sd[k].detach(), f"df_train state {k} it{it}")
+        # masks by RNG replay, then the explicit-mask path
+        torch.manual_seed(1000 + it)
+        masks = [torch.nn.functional.dropout(torch.ones(s), p, True) for s, p in zip(shapes, DT.DROPOUT_P)]
+        r2 = tr2.step(x, y, masks=masks)
+        assert r2["loss"] == r["loss"]
+        for k, v in model.state_dict().items():
+            assert_same(v, tr2.sd[k].detach(), f"df_train(masks) state {k} it{it}")
+        p_ = f"it{it}_"
+        fx[p_ + "x"] = x.numpy()[:, 0, :]
+        fx[p_ + "y"] = y.numpy()
+        for i, pk in enumerate(pack_masks(masks)):
+            fx[p_ + f"m{i}"] = pk
+        fx[p_ + "loss"] = float(loss)
+        fx[p_ + "logits"] = out.detach().numpy()
+        fx[p_ + "grad_norms"] = np.array([float(grads_ref[k].double().norm()) for k in keys])
+        fx[p_ + "param_norms"] = np.array([float(p.detach().double().norm()) for p in model.parameters()])
+        fx[p_ + "bn_stats"] = np.concatenate([v.detach().numpy().ravel() for k, v in model.state_dict().items()
+                                              if k.endswith("running_mean") or k.endswith("running_var")])
+        if it == 0:
+            for k in ("layer1.3.conv.weight", "layer2.0.conv.weight", "layer4.0.conv.weight", "layer5.0.weight",
+                      "fc.weight", "layer1.0.conv.weight", "layer3.4.weight", "layer5.1.bias"):
+                fx["it0_grad_" + k] = slices(grads_ref[k], 64)
+    fx["param_keys"] = np.array(keys)
+    np.savez_compressed(os.path.join(HERE, f"df_train_{name}.npz"), **fx)
+    print(f"   {n_steps} train steps bit-exact (loss {fx['it0_loss']:.4f} -> {fx[f'it{n_steps-1}_loss']:.4f}); wrote df_train_{name}.npz")
+
+
+# ------------------------------------------------------------------------------------------------
 def pin_script_end_to_end():
     """PIN C: unmodified reference trainer (runpy) vs oracle.train_loop.run_training, same seeds."""
     print("[script] running the unmodified reference trainer end-to-end (tiny config-1-like dataset)")
@@ -564,6 +632,9 @@ def main():
         make_sampler_case(ref_model, "tiny", 41, 5, 16, 50, seed=32)
     if not args.only or args.only == "modes":
         make_postprocess_modes(ref_model)
+    if not args.only or args.only == "df_train":
+        make_df_train_case(ref_model, "tiny", length=64, class_dim=5, batch=16, n_steps=3, seed=51)
+        make_df_train_case(ref_model, "cfg", length=1400, class_dim=100, batch=16, n_steps=2, seed=52)
     if not args.only or args.only == "gp":
         pin_gradient_penalty(ref_model)
     if not args.skip_script and (not args.only or args.only == "script"):

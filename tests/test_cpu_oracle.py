@@ -74,6 +74,33 @@ def test_oracle_epilogue_modes_match_reference_fixture(mode):
         assert np.array_equal(got, fx[f"{mode}_out"][i][: fx[f"{mode}_len"][i]]), (mode, i)
 
 
+def test_oracle_df_training_matches_reference_fixture():
+    """DF train step (reference DF module + Adamax, PIN G): the oracle with the stored masks reproduces loss, logits,
+    gradient norms and parameter norms (1e-5: another host CPU may pick other conv kernels than the one that made
+    the fixture)."""
+    import json
+    from oracle import df_train as DT
+    fx = np.load(os.path.join(GOLDEN, "df_train_tiny.npz"))
+    meta = json.loads(str(fx["meta"]))
+    L, C, B = meta["length"], meta["class_dim"], meta["batch"]
+    torch.manual_seed(meta["seed"])
+    sd0 = O.make_df_state(L, C)
+    tr = DT.DFTrainer(sd0)
+    shapes = DT.dropout_mask_shapes(L, B)
+    for it in range(meta["n_steps"]):
+        p = f"it{it}_"
+        masks = []
+        for i, (shape, pr) in enumerate(zip(shapes, DT.DROPOUT_P)):
+            bits = np.unpackbits(fx[f"{p}m{i}"])[: int(np.prod(shape))].reshape(shape)
+            masks.append(torch.from_numpy(bits.astype(np.float32)) * (1.0 / (1.0 - pr)))
+        r = tr.step(torch.from_numpy(fx[p + "x"])[:, None, :], torch.from_numpy(fx[p + "y"]), masks=masks, keep=True)
+        assert abs(r["loss"] - float(fx[p + "loss"])) <= 1e-5 * abs(float(fx[p + "loss"]))
+        assert np.abs(r["logits"].numpy() - fx[p + "logits"]).max() <= 1e-4
+        gn = np.array([float(r["grads"][k].double().norm()) for k in tr.keys])
+        big = fx[p + "grad_norms"] > 1e-6                 # biases in front of a BatchNorm carry rounding noise only
+        assert np.allclose(gn[big], fx[p + "grad_norms"][big], rtol=1e-3)
+
+
 def test_my_clip_matches_rowwise_definition():
     rng = np.random.default_rng(0)
     X = rng.integers(0, 700, size=(50, 41)).astype(np.float64)

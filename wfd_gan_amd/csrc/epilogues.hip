@@ -38,7 +38,7 @@ __device__ __forceinline__ float slab_sum(const float* __restrict__ P, int ns, l
     if (ns <= 4) return slab_tree<4>(p, ns, ss);
     if (ns <= 8) return slab_tree<8>(p, ns, ss);
     float a = slab_tree<16>(p, ns, ss);
-    for (int z = 16; z < ns; ++z) a += p[(long)z * ss];
+    for (int z = 16; z < ns; z += 16) a += slab_tree<16>(p + (long)z * ss, ns - z, ss);   // many-way splits (weight grads)
     return a;
 }
 template <int NS>
@@ -73,8 +73,8 @@ __device__ __forceinline__ float4 slab_sum4(const float* __restrict__ P, int ns,
         else if (ns <= 8) a = slab_tree4<8>(p, ns, ss);
         else {
             a = slab_tree4<16>(p, ns, ss);
-            for (int z = 16; z < ns; ++z) {
-                const float4 b0 = *reinterpret_cast<const float4*>(p + (long)z * ss);
+            for (int z = 16; z < ns; z += 16) {
+                const float4 b0 = slab_tree4<16>(p + (long)z * ss, ns - z, ss);
                 a.x += b0.x; a.y += b0.y; a.z += b0.z; a.w += b0.w;
             }
         }

@@ -105,8 +105,16 @@ __device__ __forceinline__ void load_tile(float (&r)[8], const float* __restrict
             for (int j = 0; j < 2; ++j) {
                 const int kr = (tid >> 4) + 16 * j, gk = k0 + kr, gc = row0 + 4 * (tid & 15);
                 float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-                if (gk < kend && gc < nrows) {
-                    const long off = (long)gk * ld + gc;
+                bool ok = gk < kend && gc < nrows;
+                long off = (long)gk * ld + gc;
+                if constexpr (IM2COL) {
+                    // conv weight gradient: k runs over (sample, position) rows of the channels-last activation,
+                    // the column is (tap, cin); 4 consecutive columns share a tap (Cin % 4 == 0)
+                    const int l = gk % convL, t = gc / convCin;
+                    ok = ok && (unsigned)(l + t - convPad) < (unsigned)convL;
+                    off = (long)gk * convCin + gc - (long)convPad * convCin;
+                }
+                if (ok) {
                     if (gc + 3 < nrows) {
                         v = *reinterpret_cast<const float4*>(G + off);
                     } else {
@@ -191,8 +199,8 @@ __global__ __launch_bounds__(NTHREADS) void gemm_f32_kernel(GemmArgs g) {
 
     float ra[8], rb[8];
     if (nk > 0) {
-        load_tile<AKC, VA, IM2COL>(ra, g.A, g.lda, m0, g.M, kbeg, kend, tid, g.convL, g.convCin, g.convPad);
-        load_tile<BKC, VB, false>(rb, g.B, g.ldb, n0, g.N, kbeg, kend, tid, 0, 0, 0);
+        load_tile<AKC, VA, IM2COL && AKC>(ra, g.A, g.lda, m0, g.M, kbeg, kend, tid, g.convL, g.convCin, g.convPad);
+        load_tile<BKC, VB, IM2COL && !AKC>(rb, g.B, g.ldb, n0, g.N, kbeg, kend, tid, g.convL, g.convCin, g.convPad);
         store_tile<AKC, VA>(ra, lds, tid);
         store_tile<BKC, VB>(rb, lds + TILE_F, tid);
     }
@@ -202,8 +210,8 @@ __global__ __launch_bounds__(NTHREADS) void gemm_f32_kernel(GemmArgs g) {
         const bool more = kt + 1 < nk;
         if (more) {
             const int k0 = kbeg + (kt + 1) * BK;
-            load_tile<AKC, VA, IM2COL>(ra, g.A, g.lda, m0, g.M, k0, kend, tid, g.convL, g.convCin, g.convPad);
-            load_tile<BKC, VB, false>(rb, g.B, g.ldb, n0, g.N, k0, kend, tid, 0, 0, 0);
+            load_tile<AKC, VA, IM2COL && AKC>(ra, g.A, g.lda, m0, g.M, k0, kend, tid, g.convL, g.convCin, g.convPad);
+            load_tile<BKC, VB, IM2COL && !AKC>(rb, g.B, g.ldb, n0, g.N, k0, kend, tid, g.convL, g.convCin, g.convPad);
         }
         const float* a_s = lds + cur * 2 * TILE_F;
         const float* b_s = a_s + TILE_F;
@@ -371,6 +379,27 @@ int wfd_conv8_gemm_f32_fused(const float* X, int Bn, int L, int Cin, int pad, co
     g.narrow = Cout <= 32;
     g.epi = epi; g.act = act; g.dmode = dmode; g.ldd = ldd; g.scale = scale; g.shift = shift; g.D = D;
     return launch_gemm<true, true, true>(g, 1, true, true, (hipStream_t)stream);
+}
+
+// Weight gradient of the k=8 "SAME" conv (DF observer training, src/train_df.py:121-131 backward):
+//   P[co][t*Cin + ci] = sum_{b,l} dY[b*L + l][co] * X[b][l + t - 3][ci]        (zero outside [0,L))
+// a TN product whose B operand is the channels-last activation read as its im2col matrix; the contraction runs over
+// all Bn*L rows, so it is split over gridDim.z into slabs (Cout x 8*Cin each).
+int wfd_conv8_wgrad_f32(const float* dY, const float* X, int Bn, int L, int Cin, int Cout, float* P, int ldp,
+                        long slab_stride, int splits, void* stream) {
+    if (!dY || !X || !P || Bn <= 0 || L <= 0 || Cin <= 0 || (Cin & 3) || Cout <= 0 || (Cout & 3) || splits < 1)
+        return WFD_ERR_ARG;
+    if (!aligned16(dY) || !aligned16(X) || ldp < 8 * Cin) return WFD_ERR_ARG;
+    if (splits > 1 && slab_stride < (long)Cout * ldp) return WFD_ERR_ARG;
+    GemmArgs g{};
+    g.A = dY; g.B = X; g.P = P; g.M = Cout; g.N = 8 * Cin; g.K = Bn * L; g.lda = Cout; g.ldb = 8 * Cin; g.ldp = ldp;
+    g.slab_stride = slab_stride;
+    g.ktiles_per_split = cdiv(cdiv(g.K, BK), splits);
+    g.convL = L; g.convCin = Cin; g.convPad = 3;
+    dim3 grid(cdiv(g.N, BN), cdiv(g.M, BM), splits), block(NTHREADS);
+    hipLaunchKernelGGL((gemm_f32_kernel<false, false, 4, 4, true, false, false>), grid, block, 0, (hipStream_t)stream, g);
+    WFD_CHECK_LAUNCH();
+    return WFD_OK;
 }
 
 }  // extern "C"
