@@ -250,7 +250,7 @@ int wfd_bn_tall_bwd(const float* dA, const float* Z, int M, int N, int rows_per_
 /* out[n] = sum_m X[m][n] over a tall matrix (conv bias gradients); part: ceil(M / rows_per_chunk) * N floats */
 int wfd_colsum_tall(const float* X, int ld, int M, int N, int rows_per_chunk, float* part, float* out, void* stream);
 /* weight gradient of the first conv (Cin = 1): dW[co][t] = sum_{b,l} dZ[b][l][co] * x[b][l+t-3], x[b][l] = X[b*ldx+xoff+l];
- * part: ceil(L / 256) * Bn * Cout * 8 floats */
+ * part: ceil(L / 128) * Bn * Cout * 8 floats */
 int wfd_conv1_wgrad(const float* dZ, const float* X, int ldx, int xoff, int Bn, int L, int Cout, float* part, float* dW,
                     void* stream);
 /* WT[ci][t'*Cout+co] = W[co][(7-t')*Cin+ci]: the operand of the input-gradient conv, rebuilt after every update */

@@ -47,22 +47,44 @@ __global__ void bn_tall_partial_kernel(const float* __restrict__ Z, int ldz, int
     }
 }
 
-// combine the chunks in order (Chan et al.): mean, invstd = 1/sqrt(M2/M + eps); running stats with the unbiased
-// variance, as nn.BatchNorm1d does in training mode
+// combine the chunk statistics (Chan et al.): 32 columns x 16 groups per workgroup; group g folds chunks g, g+16, ...
+// in order (loads batched eight at a time), then the 16 group results are folded in order by group 0 -- a fixed
+// association, so the result is deterministic.  mean, invstd = 1/sqrt(M2/M + eps); running stats with the unbiased
+// variance, as nn.BatchNorm1d does in training mode.
+constexpr int CG = 16;
+__device__ __forceinline__ void chan_fold(float& mu, float& m2, float& cnt, float mb, float qb, float cb) {
+    if (cb <= 0.f) return;
+    const float tot = cnt + cb, delta = mb - mu;
+    mu += delta * (cb / tot);
+    m2 += qb + delta * delta * (cnt * cb / tot);
+    cnt = tot;
+}
 __global__ void bn_tall_combine_kernel(const float* __restrict__ part, int nchunk, int rows_per_chunk, int M, int N,
                                        float eps, float momentum, float* __restrict__ mean, float* __restrict__ invstd,
                                        float* __restrict__ rmean, float* __restrict__ rvar) {
-    const int n = blockIdx.x * blockDim.x + threadIdx.x;
-    if (n >= N) return;
+    __shared__ float sh[3][CG][TC];
+    const int n = blockIdx.x * TC + threadIdx.x, g = threadIdx.y;
+    const bool ok = n < N;
     float mu = 0.f, m2 = 0.f, cnt = 0.f;
-    for (int c = 0; c < nchunk; ++c) {
-        const float cb = (float)min(rows_per_chunk, M - c * rows_per_chunk);
-        const float mb = part[((long)c * 2 + 0) * N + n], qb = part[((long)c * 2 + 1) * N + n];
-        const float tot = cnt + cb, delta = mb - mu;
-        mu += delta * (cb / tot);
-        m2 += qb + delta * delta * (cnt * cb / tot);
-        cnt = tot;
-    }
+    if (ok)
+        for (int c0 = g; c0 < nchunk; c0 += 8 * CG) {
+            float mb[8], qb[8], cb[8];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                const int c = c0 + k * CG;
+                const bool in = c < nchunk;
+                const int cc = in ? c : g;
+                mb[k] = part[((long)cc * 2 + 0) * N + n];
+                qb[k] = part[((long)cc * 2 + 1) * N + n];
+                cb[k] = in ? (float)min(rows_per_chunk, M - c * rows_per_chunk) : 0.f;
+            }
+#pragma unroll
+            for (int k = 0; k < 8; ++k) chan_fold(mu, m2, cnt, mb[k], qb[k], cb[k]);
+        }
+    sh[0][g][threadIdx.x] = mu; sh[1][g][threadIdx.x] = m2; sh[2][g][threadIdx.x] = cnt;
+    __syncthreads();
+    if (!ok || g != 0) return;
+    for (int k = 1; k < CG; ++k) chan_fold(mu, m2, cnt, sh[0][k][threadIdx.x], sh[1][k][threadIdx.x], sh[2][k][threadIdx.x]);
     mean[n] = mu;
     invstd[n] = 1.0f / sqrtf(m2 / (float)M + eps);
     if (rmean) {
@@ -118,16 +140,32 @@ __global__ void bn_tall_bwd_partial_kernel(const float* __restrict__ dA, const f
     }
 }
 
-// out[j] = sum over chunks of part[chunk][j]   (j < width), in chunk order
+// out[j] = sum over chunks of part[chunk][j]   (j < width): 32 columns x 16 groups per workgroup, group g adds chunks
+// g, g+16, ... in order (eight loads in flight), the groups are added in order through LDS (deterministic)
 __global__ void sum_partials_kernel(const float* __restrict__ part, int nchunk, int width, float* __restrict__ out,
                                     float* __restrict__ out2, int split) {
-    const int j = blockIdx.x * blockDim.x + threadIdx.x;
-    if (j >= width) return;
+    __shared__ float sh[CG][TC];
+    const int j = blockIdx.x * TC + threadIdx.x, g = threadIdx.y;
     float a = 0.f;
-    for (int c = 0; c < nchunk; ++c) a += part[(long)c * width + j];
+    if (j < width)
+        for (int c0 = g; c0 < nchunk; c0 += 8 * CG) {
+            float v[8];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                const int c = c0 + k * CG;
+                v[k] = part[(long)(c < nchunk ? c : g) * width + j];
+                if (c >= nchunk) v[k] = 0.f;
+            }
+#pragma unroll
+            for (int k = 0; k < 8; ++k) a += v[k];
+        }
+    sh[g][threadIdx.x] = a;
+    __syncthreads();
+    if (j >= width || g != 0) return;
+    for (int k = 1; k < CG; ++k) a += sh[k][threadIdx.x];
     out[j] = a;
-    // optional scatter of the two halves to separate destinations (dbeta = sums[0][:], dgamma = sums[1][:])
-    if (out2) { if (j < split) out2[j] = a; }
+    // optional copy of the first `split` entries to a second destination (dbeta = sums[0][:])
+    if (out2 && j < split) out2[j] = a;
 }
 
 // dZ = gamma * invstd * (dA - s0/M - xhat * s1/M), flat float4; sums = [s0[N] ; s1[N]]
@@ -162,22 +200,30 @@ __global__ void colsum_tall_partial_kernel(const float* __restrict__ X, int ld, 
     if (n < N && threadIdx.y == 0) part[(long)chunk * N + n] = s;
 }
 
-// first conv (Cin = 1) weight gradient partials: block (b, 256-position chunk) ->
+// first conv (Cin = 1) weight gradient partials: block (b, 128-position chunk) ->
 //   part[blk][co*8 + t] = sum_l dZ[b][l][co] * x[b][l + t - 3]
-// thread = (co, t) pair (Cout * 8 = 256 threads)
+// thread = (co, t) pair (Cout * 8 <= 1024 threads); the dZ chunk and the x window are staged in LDS with coalesced
+// loads, the products run out of LDS
+constexpr int W1CH = 128;
 __global__ void conv1_wgrad_partial_kernel(const float* __restrict__ dZ, const float* __restrict__ X, int ldx, int xoff,
-                                           int L, int Cout, int lchunk, float* __restrict__ part) {
-    extern __shared__ float xs[];          // x[l0 - 3 .. l0 + lchunk + 4)
-    const int b = blockIdx.y, l0 = blockIdx.x * lchunk, l1 = min(L, l0 + lchunk);
-    for (int i = threadIdx.x; i < lchunk + 7; i += blockDim.x) {
+                                           int L, int Cout, float* __restrict__ part) {
+    extern __shared__ float sm[];
+    float* xs = sm;                        // x[l0 - 3 .. l0 + W1CH + 4)
+    float* ds = sm + W1CH + 8;             // dZ[b][l0 .. l0 + W1CH)[Cout], row stride Cout + 1 (bank spread over t)
+    const int b = blockIdx.y, l0 = blockIdx.x * W1CH, l1 = min(L, l0 + W1CH), nl = l1 - l0;
+    for (int i = threadIdx.x; i < W1CH + 7; i += blockDim.x) {
         const int l = l0 - 3 + i;
         xs[i] = (l >= 0 && l < L) ? X[(long)b * ldx + xoff + l] : 0.f;
+    }
+    for (int i = threadIdx.x; i < nl * Cout; i += blockDim.x) {
+        const int r = i / Cout, co = i - r * Cout;
+        ds[r * (Cout + 1) + co] = dZ[((long)b * L + l0) * Cout + i];
     }
     __syncthreads();
     const int co = threadIdx.x >> 3, t = threadIdx.x & 7;
     float a = 0.f;
     if (co < Cout)
-        for (int l = l0; l < l1; ++l) a = __fmaf_rn(dZ[((long)b * L + l) * Cout + co], xs[l - l0 + t], a);
+        for (int r = 0; r < nl; ++r) a = __fmaf_rn(ds[r * (Cout + 1) + co], xs[r + t], a);
     const long blk = (long)blockIdx.y * gridDim.x + blockIdx.x;
     if (co < Cout) part[blk * (Cout * 8) + threadIdx.x] = a;
 }
@@ -250,8 +296,8 @@ int wfd_bn_tall_stats(const float* Z, int ldz, int M, int N, int rows_per_chunk,
     hipLaunchKernelGGL(bn_tall_partial_kernel, dim3(cdiv(N, TC), nchunk), dim3(TC, TR), 0, st, Z, ldz, M, N,
                        rows_per_chunk, part);
     WFD_CHECK_LAUNCH();
-    hipLaunchKernelGGL(bn_tall_combine_kernel, dim3(cdiv(N, 64)), dim3(64), 0, st, part, nchunk, rows_per_chunk, M, N, eps,
-                       momentum, mean, invstd, rmean, rvar);
+    hipLaunchKernelGGL(bn_tall_combine_kernel, dim3(cdiv(N, TC)), dim3(TC, CG), 0, st, part, nchunk, rows_per_chunk, M, N,
+                       eps, momentum, mean, invstd, rmean, rvar);
     WFD_CHECK_LAUNCH();
     return WFD_OK;
 }
@@ -276,7 +322,7 @@ int wfd_bn_tall_bwd(const float* dA, const float* Z, int M, int N, int rows_per_
     hipLaunchKernelGGL(bn_tall_bwd_partial_kernel, dim3(cdiv(N, TC), nchunk), dim3(TC, TR), 0, st, dA, Z, N, M, N,
                        rows_per_chunk, mean, invstd, part);
     WFD_CHECK_LAUNCH();
-    hipLaunchKernelGGL(sum_partials_kernel, dim3(cdiv(2 * N, 64)), dim3(64), 0, st, part, nchunk, 2 * N, sums, dbeta, N);
+    hipLaunchKernelGGL(sum_partials_kernel, dim3(cdiv(2 * N, TC)), dim3(TC, CG), 0, st, part, nchunk, 2 * N, sums, dbeta, N);
     WFD_CHECK_LAUNCH();
     // dgamma = sums[N .. 2N): a device-to-device copy node keeps the call graph-capturable
     if (hipMemcpyAsync(dgamma, sums + N, (size_t)N * sizeof(float), hipMemcpyDeviceToDevice, st) != hipSuccess)
@@ -295,7 +341,7 @@ int wfd_colsum_tall(const float* X, int ld, int M, int N, int rows_per_chunk, fl
     hipLaunchKernelGGL(colsum_tall_partial_kernel, dim3(cdiv(N, TC), nchunk), dim3(TC, TR), 0, st, X, ld, M, N,
                        rows_per_chunk, part);
     WFD_CHECK_LAUNCH();
-    hipLaunchKernelGGL(sum_partials_kernel, dim3(cdiv(N, 64)), dim3(64), 0, st, part, nchunk, N, out, (float*)nullptr, 0);
+    hipLaunchKernelGGL(sum_partials_kernel, dim3(cdiv(N, TC)), dim3(TC, CG), 0, st, part, nchunk, N, out, (float*)nullptr, 0);
     WFD_CHECK_LAUNCH();
     return WFD_OK;
 }
@@ -303,12 +349,14 @@ int wfd_colsum_tall(const float* X, int ld, int M, int N, int rows_per_chunk, fl
 int wfd_conv1_wgrad(const float* dZ, const float* X, int ldx, int xoff, int Bn, int L, int Cout, float* part, float* dW,
                     void* stream) {
     if (!dZ || !X || !part || !dW || Bn <= 0 || L <= 0 || Cout <= 0 || Cout * 8 > 1024) return WFD_ERR_ARG;
-    const int lchunk = 256, nlc = cdiv(L, lchunk);
+    const int nlc = cdiv(L, W1CH);
     hipStream_t st = (hipStream_t)stream;
-    hipLaunchKernelGGL(conv1_wgrad_partial_kernel, dim3(nlc, Bn), dim3(Cout * 8), (size_t)(lchunk + 7) * sizeof(float), st,
-                       dZ, X, ldx, xoff, L, Cout, lchunk, part);
+    const size_t lds = (size_t)(W1CH + 8 + W1CH * (Cout + 1)) * sizeof(float);
+    if (lds > 60000) return WFD_ERR_ARG;
+    hipLaunchKernelGGL(conv1_wgrad_partial_kernel, dim3(nlc, Bn), dim3(Cout * 8), lds, st, dZ, X, ldx, xoff, L, Cout,
+                       part);
     WFD_CHECK_LAUNCH();
-    hipLaunchKernelGGL(sum_partials_kernel, dim3(cdiv(Cout * 8, 64)), dim3(64), 0, st, part, nlc * Bn, Cout * 8, dW,
+    hipLaunchKernelGGL(sum_partials_kernel, dim3(cdiv(Cout * 8, TC)), dim3(TC, CG), 0, st, part, nlc * Bn, Cout * 8, dW,
                        (float*)nullptr, 0);
     WFD_CHECK_LAUNCH();
     return WFD_OK;

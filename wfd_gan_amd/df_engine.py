@@ -104,7 +104,7 @@ class DFTrainEngine:
         b["WT"] = [None] + [z(DF_CONVS[k][2], 8 * DF_CONVS[k][3]) for k in range(1, 7)]
         self.rpc = max(64, (B * Ls[0] + 1023) // 1024)                   # rows per chunk of the tall reductions
         nchunk = (B * Ls[0] + self.rpc - 1) // self.rpc
-        b["part"] = z(max(nchunk * 2 * 256, ((Ls[0] + 255) // 256) * B * 256))
+        b["part"] = z(max(nchunk * 2 * 256, ((Ls[0] + 127) // 128) * B * 256))
         b["ws"] = torch.empty(max(workspace_mb * (1 << 18), B * Ls[0] * 64), **f32)
         self.plan = self._build()
         self.graph = None
