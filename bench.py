@@ -209,7 +209,13 @@ def main():
     dt = parallel.max_over_ranks(time.perf_counter() - t0, device)
     eng.check_length_index()
     ms_per_step = dt * 1e3 / args.steps
-    its = args.steps / dt
+    steps_per_s = args.steps / dt
+    # Whole-job aggregate.  The unit is one pass of the loop body over one batch of --batch rows.  Weak scaling: every
+    # rank performs one such pass per step on its own batch (the gradient all-reduce couples them into one optimizer
+    # step on the global batch), so the job completes world passes per step.  Strong scaling: the ranks share ONE
+    # batch of --batch rows per step.
+    strong = args.dp == "strong" and world > 1
+    its = steps_per_s * (1 if strong else world)
 
     roof = gemm_roofline(eng)
     traffic = None          # HBM bytes per GEMM launch from the committed PMC passes (tools/pmc_traffic.py)
@@ -252,7 +258,8 @@ def main():
 
     if rank == 0:
         out = {
-            "metric": "WGAN train iterations/s (100-class, L=1400, B=64/GPU, fp32; D-step every iter, G-step every 3rd)",
+            "metric": "WGAN train iterations/s (100-class, L=1400, fp32; one iteration = loop body on one 64-row batch: "
+                      "D-step every iteration, G-step every 3rd; N GPUs weak-scaled = N such batches per optimizer step)",
             "value": its * 1.0, "unit": "iterations/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "strong" if (args.dp == "strong" and world > 1) else "weak",
             "vs_baseline": None,
@@ -260,7 +267,8 @@ def main():
             "config": {"workload": "configs[1]: 100 sites x 1000 inst synthetic bursts, L=1400 (S=1401), batch "
                                    f"{args.batch}/GPU, latent {args.latent_dim}, n_critic 3, alpha 0.02, RMSprop 2e-4, "
                                    f"penalty={args.penalty} ({'W-div k=2 p=6, what the reference runs' if args.penalty == 'div' else 'WGAN-GP interpolate'})",
-                       "global_batch": eng.B * world, "samples_per_s": its * eng.B * world,
+                       "global_batch": eng.B * world, "optimizer_steps_per_s": steps_per_s,
+                       "samples_per_s": steps_per_s * eng.B * world,
                        "parallelism": f"dp{world}", "graphs": not args.no_graph},
             "roofline": {"bound": "mfma", "achieved": roof["tflops"], "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
                          "frac": roof["tflops"] / PEAK_F32_MFMA_TFLOPS, "traffic": traffic,

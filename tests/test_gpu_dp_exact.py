@@ -117,3 +117,31 @@ def test_trainer_cli_two_ranks(tmp_path, mode):
     assert all(len(ls[k]) == 2 and np.isfinite(ls[k]).all() for k in ("generator", "discriminator", "dist"))
     assert len(glob.glob(os.path.join(out, "model", "generator_seqlen41_cls5_latentdim24.ckpt"))) == 1
     assert len(glob.glob(str(tmp_path / "ds" / "training_*"))) == 1          # only rank 0 made an output directory
+
+
+@pytest.mark.parametrize("mode", ["weak", "strong"])
+def test_bench_two_ranks_share_one_gpu(mode):
+    """bench.py under a 2-rank launch (the driver's N > 1 form), here with both ranks on cuda:0 over gloo: the
+    data-parallel plans, graph stages, bucketed gradient sync and the JSON contract."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    port = _free_port()
+    procs = []
+    for r in range(2):
+        env = dict(os.environ, RANK=str(r), WORLD_SIZE="2", LOCAL_RANK="0", MASTER_ADDR="127.0.0.1",
+                   MASTER_PORT=str(port), WFD_DIST_BACKEND="gloo")
+        procs.append(subprocess.Popen([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "6",
+                                       "--warmup", "3", "--inst", "20", "--no-sampling", "--no-cpu-baseline", "--dp",
+                                       mode], env=env, cwd=root, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True))
+    outs = [p.communicate(timeout=280) for p in procs]
+    assert all(p.returncode == 0 for p in procs), "\n".join(o[1][-2000:] for o in outs)
+    line = [ln for ln in outs[0][0].splitlines() if ln.startswith("{")][-1]
+    res = json.loads(line)
+    assert res["n_gpus"] == 2 and res["scaling"] == mode and res["value"] > 0
+    assert res["config"]["global_batch"] == (128 if mode == "weak" else 64)
+    steps = res["config"]["optimizer_steps_per_s"]
+    assert abs(res["value"] - steps * (2 if mode == "weak" else 1)) < 1e-6 * res["value"]
+    assert not [ln for ln in outs[1][0].splitlines() if ln.startswith("{")]          # only rank 0 prints

@@ -122,7 +122,7 @@ def max_over_ranks(value: float, device) -> float:
     """Timing convention of bench.py: the slowest rank defines the step time."""
     if not (dist.is_available() and dist.is_initialized()):
         return value
-    t = torch.tensor([value], dtype=torch.float64, device=device)
+    t = torch.tensor([value], dtype=torch.float64, device="cpu" if dist.get_backend() == "gloo" else device)
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
     return float(t.item())
 
@@ -130,7 +130,7 @@ def max_over_ranks(value: float, device) -> float:
 def sum_over_ranks(value: float, device) -> float:
     if not (dist.is_available() and dist.is_initialized()):
         return value
-    t = torch.tensor([value], dtype=torch.float64, device=device)
+    t = torch.tensor([value], dtype=torch.float64, device="cpu" if dist.get_backend() == "gloo" else device)
     dist.all_reduce(t, op=dist.ReduceOp.SUM)
     return float(t.item())
 
