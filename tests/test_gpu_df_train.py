@@ -173,3 +173,11 @@ def test_train_df_cli_learns(tmp_path):
     torch.manual_seed(0)
     assert list(sd.keys()) == list(O.make_df_state(L, n_cls).keys())
     DF(L, n_cls).load_state_dict(sd, strict=True)
+    # the whole user workflow: that checkpoint is the --f_model of the GAN trainer, whose generator then samples
+    from wfd_gan_amd import generate, mlp_df_wgan_train
+    run = mlp_df_wgan_train.main(["-d", npz, "--f_model", out, "--n_epochs", "1", "--batch_size", "32", "--latent_dim",
+                                  "16", "--seed", "3"])
+    assert os.path.isfile(os.path.join(run, "checkpoint", "epoch_1.npz"))
+    ts = generate.TraceSampler(os.path.join(run, "model"), device=DEV, chunk=64, mode="wt")
+    outs, lens = ts.sample_many(torch.arange(64) % n_cls)
+    assert outs.shape == (64, L + 1) and bool((lens % 2 == 0).all())
