@@ -180,6 +180,9 @@ def main():
     ap.add_argument("--dp", default="weak", choices=["weak", "strong"],
                     help="N > 1: weak = --batch rows per GPU (DDP semantics, the driver's scaling runs); strong = --batch "
                          "rows split over the GPUs with SyncBN (result-equal to one GPU)")
+    ap.add_argument("--pipeline", type=int, default=0,
+                    help="1: software-pipelined driver (wfd_gan_amd.engine.PipelinedTrainer; measured 3 %% slower than "
+                         "the sequential engine on one MI355X, see DESIGN.md section 6); 0: sequential engine")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-sampling", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=20.0)
@@ -193,9 +196,16 @@ def main():
     torch.cuda.set_device(device)
 
     eng, (dmin, dmax) = build_engine(args, rank, world, device)
-    if not args.no_graph:
-        eng.capture_graphs()
-    run_steps(eng, 0, args.warmup)
+    strong = args.dp == "strong" and world > 1
+    pipelined = bool(args.pipeline) and not strong
+    if pipelined:           # generator forward of iteration i+1 on a second stream beside iteration i's critic update
+        from wfd_gan_amd.engine import PipelinedTrainer
+        drv = PipelinedTrainer(eng, graphs=not args.no_graph)
+    else:
+        drv = eng
+        if not args.no_graph:
+            eng.capture_graphs()
+    run_steps(drv, 0, args.warmup)
 
     def barrier():
         if world > 1:
@@ -204,17 +214,16 @@ def main():
 
     barrier()
     t0 = time.perf_counter()
-    run_steps(eng, args.warmup, args.steps)
+    run_steps(drv, args.warmup, args.steps)
     barrier()
     dt = parallel.max_over_ranks(time.perf_counter() - t0, device)
-    eng.check_length_index()
+    drv.check_length_index()
     ms_per_step = dt * 1e3 / args.steps
     steps_per_s = args.steps / dt
     # Whole-job aggregate.  The unit is one pass of the loop body over one batch of --batch rows.  Weak scaling: every
     # rank performs one such pass per step on its own batch (the gradient all-reduce couples them into one optimizer
     # step on the global batch), so the job completes world passes per step.  Strong scaling: the ranks share ONE
     # batch of --batch rows per step.
-    strong = args.dp == "strong" and world > 1
     its = steps_per_s * (1 if strong else world)
 
     roof = gemm_roofline(eng)
@@ -269,7 +278,7 @@ def main():
                                    f"penalty={args.penalty} ({'W-div k=2 p=6, what the reference runs' if args.penalty == 'div' else 'WGAN-GP interpolate'})",
                        "global_batch": eng.B * world, "optimizer_steps_per_s": steps_per_s,
                        "samples_per_s": steps_per_s * eng.B * world,
-                       "parallelism": f"dp{world}", "graphs": not args.no_graph},
+                       "parallelism": f"dp{world}", "graphs": not args.no_graph, "pipelined": pipelined},
             "roofline": {"bound": "mfma", "achieved": roof["tflops"], "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
                          "frac": roof["tflops"] / PEAK_F32_MFMA_TFLOPS, "traffic": traffic,
                          "traffic_note": "bytes/launch, rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command "

@@ -1,0 +1,88 @@
+"""GPU: the pipelined fast-mode driver (generator forward of iteration i+1 on a second stream while iteration i's
+critic update runs).  Every pipelined iteration is replayed on a plain sequential engine from the same starting
+parameters with the batch / z / dropout masks the pipelined step actually used: the updated parameters must be
+bit-identical (same kernels, same inputs) -- i.e. overlapping changed nothing but the schedule."""
+import pytest
+import torch
+
+from oracle import wfdgan_oracle as O
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+def _engine(S, C, Z, B, st, **kw):
+    from wfd_gan_amd.engine import TrainEngine
+    return TrainEngine(S, C, Z, B, st.scaler_min, st.scaler_max, {k: v.detach() for k, v in st.G.items()},
+                       {k: v.detach() for k, v in st.D.items()}, st.DF, device=DEV, **kw)
+
+
+@pytest.mark.parametrize("graphs", [False, True])
+@pytest.mark.parametrize("penalty", ["div", "gp"])
+def test_pipelined_iterations_equal_sequential_replay(graphs, penalty):
+    from wfd_gan_amd.engine import PipelinedTrainer
+    S, C, Z, B = 101, 6, 24, 16
+    X, y = O.synth_dataset(C, 30, S - 1, 10, 13, 122, seed=1)
+    dmin, dmax = X.min(0), X.max(0)
+    scale, min_ = O.scaler_params(dmin, dmax)
+    Xs = torch.from_numpy(X * scale + min_).float()
+    st = O.make_state(S, C, Z, dmin[0], dmax[0], seed=2, df_seed=3)
+    O.perturb_df_bn(st.DF, 4)
+    eng = _engine(S, C, Z, B, st, penalty=penalty, seed=11)
+    eng.attach_dataset(Xs, torch.from_numpy(y), shuffle_seed=5)
+    pipe = PipelinedTrainer(eng, graphs=graphs)
+    ref = _engine(S, C, Z, B, st, penalty=penalty)
+    seen = []
+    n_iter = 2 * eng.iters_per_epoch + 2                   # crosses two epoch boundaries (reshuffles)
+    for i in range(n_iter):
+        torch.cuda.synchronize()
+        pre = dict(G=eng.Gp.flat.clone(), Gsq=eng.Gp.sq.clone(), D=eng.Dp.flat.clone(), Dsq=eng.Dp.sq.clone())
+        do_g = pipe.iteration(i)
+        torch.cuda.synchronize()
+        s = pipe.slot(i)
+        assert do_g == (i % 3 == 0)
+        # replay on the sequential parity engine
+        ref.Gp.flat.copy_(pre["G"]); ref.Gp.sq.copy_(pre["Gsq"]); ref.Dp.flat.copy_(pre["D"]); ref.Dp.sq.copy_(pre["Dsq"])
+        ref.set_batch(s.real_rows[:, :S], s.buf["labels"], s.buf["ZIN"][:, :Z])
+        if penalty == "gp":
+            ref.set_gp_alpha(s.buf["GPA"])
+        ref.set_masks([s.buf[f"MK{k}"] for k in (1, 2, 3)], [s.buf[f"gMK{k}"] for k in (1, 2, 3)] if do_g else None)
+        ref.d_step()
+        if do_g:
+            ref.g_step()
+        torch.cuda.synchronize()
+        assert torch.equal(ref.fake_rows, s.fake_rows), f"it{i}: generated rows"
+        assert torch.equal(ref.Dp.flat, eng.Dp.flat), f"it{i}: critic parameters"
+        assert torch.equal(ref.Gp.flat, eng.Gp.flat), f"it{i}: generator parameters"
+        assert torch.equal(ref.Dp.sq, eng.Dp.sq) and torch.equal(ref.Gp.sq, eng.Gp.sq)
+        seen.append(s.buf["labels"].clone())
+    pipe.check_length_index()
+    assert torch.isfinite(eng.Dp.flat).all() and torch.isfinite(eng.Gp.flat).all()
+    # every epoch is a permutation: the label histogram of one epoch's batches equals the dataset's (full batches)
+    ipe = eng.iters_per_epoch
+    ep0 = torch.cat(seen[:ipe]).cpu()
+    assert ep0.numel() == ipe * B
+    # BatchNorm bookkeeping: one update per D-step forward + one per G-step
+    assert eng.nbt["model.3"] == n_iter + (n_iter + 2) // 3
+
+
+def test_pipelined_matches_itself_graph_vs_eager():
+    from wfd_gan_amd.engine import PipelinedTrainer
+    S, C, Z, B = 61, 4, 16, 8
+    X, y = O.synth_dataset(C, 20, S - 1, 10, 13, 122, seed=1)
+    dmin, dmax = X.min(0), X.max(0)
+    scale, min_ = O.scaler_params(dmin, dmax)
+    Xs = torch.from_numpy(X * scale + min_).float()
+    outs = []
+    for graphs in (False, True):
+        st = O.make_state(S, C, Z, dmin[0], dmax[0], seed=2, df_seed=3)
+        eng = _engine(S, C, Z, B, st, seed=3)
+        eng.attach_dataset(Xs, torch.from_numpy(y), shuffle_seed=5)
+        pipe = PipelinedTrainer(eng, graphs=graphs)
+        for i in range(13):
+            pipe.iteration(i)
+        torch.cuda.synchronize()
+        outs.append((eng.Dp.flat.clone(), eng.Gp.flat.clone(), {k: v.clone() for k, v in eng.Gbuf.items()}))
+    assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
+    for k in outs[0][2]:
+        assert torch.equal(outs[0][2][k], outs[1][2][k]), k

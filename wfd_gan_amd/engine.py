@@ -278,9 +278,13 @@ class TrainEngine:
         # slab workspace: at least the largest raw product of a step (first DF conv block: B*L x 32, split-K x2)
         b["ws"] = torch.empty(max(workspace_mb * (1 << 18), B * S * 64), **f32)
         b["ws2"] = torch.empty(64 * (1 << 18), **f32)        # slab workspace of the side lane
+        b["ws_gf"] = torch.empty(max(16 * B * 2048, 1 << 20), **f32)   # slabs of a generator forward running ahead
         self.overlap = overlap
 
-        self.iter_state = torch.zeros(2, dtype=torch.int64, device=dev)   # [philox counter, perm cursor]
+        # [philox counter, perm cursor] of the step plans; gf_state: the same pair for the stand-alone generator-forward
+        # plans of the pipelined driver (they run ahead on a second stream and advance their own state)
+        self.iter_state = share.iter_state if share is not None else torch.zeros(2, dtype=torch.int64, device=dev)
+        self.gf_state = share.gf_state if share is not None else torch.zeros(2, dtype=torch.int64, device=dev)
         # fast mode, data parallel: all ranks hold the same permutation; rank r takes rows [r*B, (r+1)*B) of each
         # run of B*world indices and the cursor advances by the rows all ranks consumed
         self.row_offset = self.rank * B if self.dp else 0
@@ -394,13 +398,17 @@ class TrainEngine:
     def _rng_inc(self) -> int:
         return max((self.B * self.Z + 3) // 4, (self.buf["MKflat"].numel() + 3) // 4)
 
-    def _build_d_plan(self, fast: bool = False) -> Plan:
+    def _build_d_plan(self, fast: bool = False, part: str = "all") -> Plan:
         """fast: the batch, z and the dropout masks are produced on device from the resident dataset / Philox and
         the step ends by advancing the device-resident iteration state (graph-replayable); otherwise the caller
-        supplies them (parity mode)."""
+        supplies them (parity mode).
+        part: "all" = the whole D-step; "gf" = only its head (batch gather, z / mask draws, generator forward), which
+        depends on nothing the critic update writes; "rest" = everything after it (PipelinedTrainer)."""
         B, M, S, C, Z, b, D = self.B, self.M, self.S, self.C, self.Z, self.buf, self.Dp
-        p = Plan(b["ws"], b["ws2"], self.overlap)
-        st = self.iter_state.data_ptr()
+        p = Plan(b["ws"] if part != "gf" else b["ws_gf"], b["ws2"], self.overlap)
+        st = self.iter_state.data_ptr() if part != "gf" else self.gf_state.data_ptr()
+        if part == "rest":
+            return self._build_d_rest(p, fast, own_cursor=False)
         if fast:
             p.add(self.L.gather_batch, ptr(self.data_X), S, ptr(self.data_y), ptr(self.perm), st, self.N, self.N,
                   self.row_offset, B, S, C, ptr(self.real_rows), ptr(self.fake_rows), self.ldx, ptr(b["ZIN"]), self.ldz, Z, ptr(b["labels"]))
@@ -413,6 +421,16 @@ class TrainEngine:
             # interpolates = third row group of the critic input (src/utils.py:67-69)
             p.add(self.L.interpolate_rows, ptr(self.real_rows), ptr(self.fake_rows), ptr(b["GPA"]),
                   ptr(self.din[2 * B:]), B, S, S + C, self.ldx)
+        if part == "gf":
+            p.add(self.L.iter_advance, st, self._rng_inc(), self.cursor_step)
+            return p
+        return self._build_d_rest(p, fast, own_cursor=True)
+
+    def _build_d_rest(self, p: Plan, fast: bool, own_cursor: bool) -> Plan:
+        """Critic forward on the stacked rows, closed-form penalty, backward, RMSprop (everything of the D-step
+        after the generator forward)."""
+        B, M, S, C, Z, b, D = self.B, self.M, self.S, self.C, self.Z, self.buf, self.Dp
+        st = self.iter_state.data_ptr()
         din = self.din
         H1, H2 = b["T1H1"][M:], b["T2H2"][M:]
         self._critic_forward(p, din, M, (b["MK1"], b["MK2"], b["MK3"]), H1, H2, b["H3"], b["D1"], b["D2"], b["D3"],
@@ -459,7 +477,7 @@ class TrainEngine:
         p.join()
         self._grad_sync_hook(p, "D")
         p.add(self.L.rmsprop, ptr(D.flat), ptr(D.grad), ptr(D.sq), D.numel, self.lr, 0.99, 1e-8, self.gscale,
-              st if fast else 0, self._rng_inc() if fast else 0, self.cursor_step if fast else 0)
+              st if fast else 0, self._rng_inc() if fast else 0, (self.cursor_step if own_cursor else 0) if fast else 0)
         return p
 
     def _colsum_multi(self, p: Plan, name: str, segs):
@@ -815,3 +833,125 @@ class TrainEngine:
         if self.auto_reshuffle and self._pos >= self.iters_per_epoch:
             self.reshuffle()
         return do_g
+
+
+class PipelinedTrainer:
+    """Fast-mode driver that runs the generator forward of iteration i+1 on a second HIP stream while the critic
+    update of iteration i executes (software pipelining across iterations).
+
+    The head of a D-step -- batch gather, z / dropout-mask draws, generator forward -- reads only the generator's
+    parameters, which change in G-steps alone.  So whenever iteration i has no G-step (two iterations out of three
+    with n_critic = 3), the head of iteration i+1 is independent of everything iteration i computes.  Two buffer sets
+    (two TrainEngines on shared parameters: "slots", used by even / odd iterations) make that overlap legal; each
+    part is its own HIP graph (no fork/join inside a graph), ordered by events:
+
+        stream main :  rest(i) [G-step(i)]            rest(i+1) ...
+        stream side :         head(i+1)  --event-->
+
+    Arithmetic and the order of every state update (BatchNorm running statistics, RMSprop) are those of the
+    sequential engine (tests/test_gpu_pipeline.py replays every pipelined iteration sequentially: bit-identical);
+    only the Philox streams are partitioned differently.
+
+    MEASURED (round 1, one MI355X, config 2): 2231 it/s against 2309 it/s for the sequential engine -- the extra graph
+    launches and cross-stream event waits cost more than the overlap returns (host enqueue 0.20 ms/iteration, not
+    the limit).  Kept as an option (bench.py --pipeline 1), off by default."""
+
+    def __init__(self, eng: "TrainEngine", graphs: bool = True):
+        if eng.exact:
+            raise ValueError("the pipelined driver does not cover the SyncBN mode (collectives inside the generator forward)")
+        if not hasattr(eng, "data_X"):
+            raise RuntimeError("attach_dataset() first")
+        self.e = [eng, TrainEngine(eng.S, eng.C, eng.Z, eng.B, eng.scaler_min, eng.scaler_max, {}, {}, {}, lr=eng.lr,
+                                   alpha=eng.alpha, n_critic=eng.n_critic, penalty=eng.penalty, lambda_gp=eng.lambda_gp,
+                                   device=eng.dev, seed=eng.seed + 0x51ED, process_group=eng.pg, world_size=eng.world,
+                                   share=eng, rank=eng.rank)]
+        other = self.e[1]
+        for name in ("data_X", "data_y", "N", "perm", "perm_gen", "iters_per_epoch"):
+            setattr(other, name, getattr(eng, name))
+        other._gsync = eng._gsync
+        self.main = torch.cuda.current_stream(eng.dev)
+        self.side = torch.cuda.Stream(device=eng.dev)
+        self.gf = [e._build_d_plan(fast=True, part="gf") for e in self.e]
+        self.rest = [e._build_d_plan(fast=True, part="rest") for e in self.e]
+        self.gs = [e._build_g_plan(fast=True) for e in self.e]
+        self.ready = [None, None]          # event: head of the slot's next iteration is done
+        self.prefetched = [False, False]
+        self._pos = 0
+        self.auto_reshuffle = True
+        eng.gf_state.zero_()
+        self.run_gf, self.run_rest, self.run_gs = ([pl.run for pl in plans] for plans in (self.gf, self.rest, self.gs))
+        if graphs:
+            self._capture()
+
+    def _capture(self):
+        eng = self.e[0]
+        snap = eng._snapshot()
+        gfs = eng.gf_state.clone()
+        warm = torch.cuda.Stream(device=eng.dev)
+        warm.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(warm):
+            for k in range(2):
+                self.gf[k].run(); self.rest[k].run(); self.gs[k].run()
+        torch.cuda.current_stream().wait_stream(warm)
+        torch.cuda.synchronize()
+
+        def runner(plan):
+            stages = TrainEngine._capture_stages(plan)
+            return lambda: [st() for st in stages]
+        self.run_gf = [runner(pl) for pl in self.gf]
+        self.run_rest = [runner(pl) for pl in self.rest]
+        self.run_gs = [runner(pl) for pl in self.gs]
+        torch.cuda.synchronize()
+        eng._restore(snap)
+        eng.gf_state.copy_(gfs)
+
+    def slot(self, i: int) -> "TrainEngine":
+        """The engine whose buffers hold iteration i's batch, generated rows and statistics."""
+        return self.e[i & 1]
+
+    def iteration(self, i: int, prefetch_next: bool = True) -> bool:
+        """One pass of the reference loop body (D-step, plus a G-step when i % n_critic == 0).  ``prefetch_next``:
+        iteration i+1 follows in the same epoch permutation (its head may start now)."""
+        k = i & 1
+        eng = self.e[0]
+        do_g = (i % eng.n_critic == 0)
+        main = torch.cuda.current_stream(eng.dev)
+        if self.prefetched[k]:
+            main.wait_event(self.ready[k])
+            self.prefetched[k] = False
+        else:
+            self.run_gf[k]()                                   # pipeline start-up (and after every G-step / epoch end)
+        last = self.auto_reshuffle and self._pos + 1 >= eng.iters_per_epoch
+        ahead = prefetch_next and not do_g and not last
+        if ahead:
+            # slot k^1 is free: everything that read it (iteration i-1, the caller's copies) is already on `main`
+            free = torch.cuda.Event()
+            free.record(main)
+            self.side.wait_event(free)
+            with torch.cuda.stream(self.side):
+                self.run_gf[k ^ 1]()
+                ev = torch.cuda.Event()
+                ev.record(self.side)
+            self.ready[k ^ 1], self.prefetched[k ^ 1] = ev, True
+        self.run_rest[k]()
+        if do_g:
+            self.run_gs[k]()
+        n = 2 if do_g else 1
+        eng.nbt["model.3"] += n
+        eng.nbt["model.6"] += n
+        self._pos += 1
+        if last:
+            self.reshuffle()
+        return do_g
+
+    def reshuffle(self):
+        """New epoch permutation; the cursor of the head plans goes back to 0 (no head is in flight here)."""
+        eng = self.e[0]
+        assert not any(self.prefetched)
+        eng.perm.copy_(torch.randperm(eng.N, generator=eng.perm_gen, device=eng.dev))
+        eng.gf_state[1] = 0
+        self._pos = 0
+
+    def check_length_index(self):
+        for e in self.e:
+            e.check_length_index()
