@@ -72,8 +72,17 @@ def build_engine(args, rank, world, device):
 
 
 def run_steps(eng, start, n):
-    for i in range(start, start + n):
-        eng.iteration(i)          # re-permutes by itself at epoch ends
+    """n iterations from iteration index `start`; whole groups of n_critic iterations go out as one graph replay
+    where the engine offers it (re-permutes by itself at epoch ends)."""
+    i, end = start, start + n
+    group = getattr(eng, "iteration_group", None)
+    nc = getattr(eng, "n_critic", 3)
+    while i < end:
+        if group is not None and i % nc == 0 and i + nc <= end:
+            i += group(i)
+        else:
+            eng.iteration(i)
+            i += 1
 
 
 def gemm_roofline(eng, rep=16, rounds=3):

@@ -86,3 +86,31 @@ def test_pipelined_matches_itself_graph_vs_eager():
     assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
     for k in outs[0][2]:
         assert torch.equal(outs[0][2][k], outs[1][2][k]), k
+
+
+def test_group_graph_equals_single_iterations():
+    """iteration_group (one graph replay per n_critic iterations) == the same iterations one by one, across an
+    epoch boundary (where it falls back to single iterations)."""
+    S, C, Z, B = 61, 4, 16, 8
+    X, y = O.synth_dataset(C, 20, S - 1, 10, 13, 122, seed=1)          # 80 rows -> 10 iterations per epoch
+    dmin, dmax = X.min(0), X.max(0)
+    scale, min_ = O.scaler_params(dmin, dmax)
+    Xs = torch.from_numpy(X * scale + min_).float()
+    outs = []
+    for grouped in (False, True):
+        st = O.make_state(S, C, Z, dmin[0], dmax[0], seed=2, df_seed=3)
+        eng = _engine(S, C, Z, B, st, seed=3)
+        eng.attach_dataset(Xs, torch.from_numpy(y), shuffle_seed=5)
+        eng.capture_graphs()
+        assert eng.graph_group is not None
+        i = 0
+        while i < 24:
+            if grouped:
+                i += eng.iteration_group(i)
+            else:
+                eng.iteration(i)
+                i += 1
+        torch.cuda.synchronize()
+        outs.append((eng.Dp.flat.clone(), eng.Gp.flat.clone(), dict(eng.nbt), eng.iter_state.clone()))
+    assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
+    assert outs[0][2] == outs[1][2] and torch.equal(outs[0][3], outs[1][3])

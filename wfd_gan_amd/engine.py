@@ -292,7 +292,7 @@ class TrainEngine:
         self._fill_row_constants()
         self.plan_d = self._build_d_plan()
         self.plan_g = self._build_g_plan()
-        self.graph_d = self.graph_g = None
+        self.graph_d = self.graph_g = self.graph_group = None
 
     # ------------------------------------------------------------------------------------------------------
     @property
@@ -796,6 +796,17 @@ class TrainEngine:
         torch.cuda.synchronize()
         self.graph_d = self._capture_stages(self.fast_d)
         self.graph_g = self._capture_stages(self.fast_g)
+        # one graph for a whole group of n_critic iterations (D G D ... D), when no host action splits the plans:
+        # saves the graph-launch boundaries inside the group (iteration_group)
+        self.graph_group = None
+        if len(self.graph_d) == 1 and len(self.graph_g) == 1:
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g):
+                self.fast_d.run()
+                self.fast_g.run()
+                for _ in range(self.n_critic - 1):
+                    self.fast_d.run()
+            self.graph_group = g
         torch.cuda.synchronize()
         self._restore(snap)
 
@@ -833,6 +844,24 @@ class TrainEngine:
         if self.auto_reshuffle and self._pos >= self.iters_per_epoch:
             self.reshuffle()
         return do_g
+
+    def iteration_group(self, i: int) -> int:
+        """Iterations i .. i + n_critic - 1 (i a multiple of n_critic: G-step after the first D-step) as ONE graph
+        replay when available and the group stays inside the epoch permutation; otherwise n_critic single iterations.
+        For throughput runs: the generated rows of the G-step are overwritten by the following D-steps, so a caller
+        that collects them (the trainer) uses iteration().  Returns the number of iterations done."""
+        n = self.n_critic
+        if self.graph_group is None or i % n != 0 or (self.auto_reshuffle and self._pos + n > self.iters_per_epoch):
+            for k in range(n):
+                self.iteration(i + k)
+            return n
+        self.graph_group.replay()
+        self.nbt["model.3"] += n + 1
+        self.nbt["model.6"] += n + 1
+        self._pos += n
+        if self.auto_reshuffle and self._pos >= self.iters_per_epoch:
+            self.reshuffle()
+        return n
 
 
 class PipelinedTrainer:
