@@ -13,14 +13,18 @@ def init_logger(name, log_dir=None):
     logger = logging.getLogger(name)
     logger.setLevel(logging.DEBUG)
     fmt = logging.Formatter(cm.LOG_FORMAT)
-    if not logger.handlers:
-        console = logging.StreamHandler()
-        console.setFormatter(fmt)
-        logger.addHandler(console)
-        if log_dir is not None:
-            fileh = logging.StreamHandler(open(log_dir, "w"))
-            fileh.setFormatter(fmt)
-            logger.addHandler(fileh)
+    # a second run in the same process (tests, notebooks) gets its own log file, not the first run's
+    for h in list(logger.handlers):
+        logger.removeHandler(h)
+        if isinstance(h, logging.FileHandler):
+            h.close()
+    console = logging.StreamHandler()
+    console.setFormatter(fmt)
+    logger.addHandler(console)
+    if log_dir is not None:
+        fileh = logging.FileHandler(log_dir, mode="w")
+        fileh.setFormatter(fmt)
+        logger.addHandler(fileh)
     return logger
 
 
