@@ -41,6 +41,10 @@ int wfd_gemm_f32(int layout, const float* A, int lda, const float* B, int ldb, f
 int wfd_conv8_gemm_f32(const float* X, int Bn, int L, int Cin, int pad, const float* Wp, int Cout, float* P, int ldp,
                        long slab_stride, int splits, void* stream);
 
+/* 1 when the conv entry points below run an (M = Bn*L, Cin, Cout) conv with the LDS-resident kernel (Cin = 32 on a long
+ * sequence: input rows and the weight tile stay in LDS, no K split): take the fused single-launch form then */
+int wfd_conv8_direct(int M, int Cin, int Cout);
+
 /* The same contractions with the consumer's element-wise math fused into the store (single split: no slab round
  * trip, one launch less): epi 1 = wfd_ep_affine_act (scale/shift/act), epi 2 = wfd_ep_mul (D/dmode/scale, no second
  * copy).  Used where the product alone fills the chip (DF convs over B*L rows, large-batch Linear layers). */

@@ -125,3 +125,42 @@ def test_gemm_fused_epilogues(N):
                          Dd.data_ptr(), N, dmode, st)
         want = f(raw) * scale.double()
         assert (out.cpu().double() - want).abs().max().item() < 1e-4
+
+
+@pytest.mark.parametrize("cfg", [(13, 1400, 32), (40, 437, 64), (130, 129, 96)])
+@pytest.mark.parametrize("pad", [3, 4])
+def test_conv8_lds_resident_kernel(cfg, pad):
+    """Cin = 32 on enough 128-row tiles takes the LDS-resident kernel (input rows + weight tile in LDS): samples whose
+    length is no multiple of the tile (taps crossing a sample edge inside a tile must read zero), Cout beyond one
+    32-column tile and not a multiple of 64, raw and fused epilogues."""
+    from wfd_gan_amd._lib import lib
+    import torch.nn.functional as F
+    L = lib()
+    Bn, Ln, Cout = cfg
+    Cin = 32
+    M = Bn * Ln
+    assert L.conv8_direct(M, Cin, Cout) == 1
+    g = torch.Generator().manual_seed(2)
+    x = torch.randn(Bn, Cin, Ln, generator=g)
+    w = torch.randn(Cout, Cin, 8, generator=g)
+    ref = F.conv1d(F.pad(x.double(), (pad, 7 - pad)), w.double()).permute(0, 2, 1).reshape(M, Cout)
+    xcl = x.permute(0, 2, 1).contiguous().to("cuda:0")
+    wp = w.permute(0, 2, 1).reshape(Cout, 8 * Cin).contiguous().to("cuda:0")
+    st = torch.cuda.current_stream().cuda_stream
+    P = torch.full((M, Cout), float("nan"), device="cuda:0")
+    L.conv8_gemm_f32(xcl.data_ptr(), Bn, Ln, Cin, pad, wp.data_ptr(), Cout, P.data_ptr(), Cout, 0, 1, st)
+    torch.cuda.synchronize()
+    scale_ref = ref.abs().max().item()
+    assert (P.cpu().double() - ref).abs().max().item() / scale_ref < 2e-5
+    scale, shift = torch.rand(Cout, generator=g) + 0.5, torch.randn(Cout, generator=g)
+    D = torch.randn(M, Cout, generator=g)
+    sd, hd, Dd = scale.to("cuda:0"), shift.to("cuda:0"), D.to("cuda:0")
+    out = torch.full((M, Cout), float("nan"), device="cuda:0")
+    L.conv8_gemm_f32_fused(xcl.data_ptr(), Bn, Ln, Cin, pad, wp.data_ptr(), Cout, out.data_ptr(), Cout, 1, sd.data_ptr(),
+                           hd.data_ptr(), 2, 0, 0, 0, st)
+    want = F.elu(ref * scale.double() + shift.double())
+    assert (out.cpu().double() - want).abs().max().item() / scale_ref < 2e-5
+    L.conv8_gemm_f32_fused(xcl.data_ptr(), Bn, Ln, Cin, pad, wp.data_ptr(), Cout, out.data_ptr(), Cout, 2, sd.data_ptr(),
+                           0, 0, Dd.data_ptr(), Cout, 3, st)
+    want = ref * torch.where(D > 0, torch.ones(()), D + 1).double() * scale.double()
+    assert (out.cpu().double() - want).abs().max().item() / scale_ref < 2e-5

@@ -278,6 +278,86 @@ int launch_gemm2(const GemmArgs& g, int splits, bool va4, bool vb4, hipStream_t 
     return WFD_OK;
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// k=8 "SAME" conv with Cin = 32 on a long sequence (the DF observer's first block at L = 1400: M = B*L rows, K = 256):
+// the implicit-GEMM form above re-reads every activation row eight times (once per tap) from L2 and streams the
+// weights per k-tile.  Here a workgroup keeps its 128 + 7 input rows AND the 32 x 256 weight tile in LDS
+// (19.4 + 33.3 KB), so the K loop touches no global memory and has no barrier: the A fragment of tap t is the SAME
+// LDS tile read t rows further down.  4 waves x (32 rows x 32 columns), 128 MFMAs each.
+// Rows are flattened (sample, position) pairs; a tap that would cross a sample edge is zeroed per lane.
+constexpr int C32 = 32, C32_ROWS = 128, XS_LD = C32 + 4, WS_LD = 8 * C32 + 4;
+constexpr int C32_LDS_FLOATS = (C32_ROWS + 7) * XS_LD + 32 * WS_LD;
+
+template <bool EPI>
+__global__ __launch_bounds__(NTHREADS) void conv8_c32_kernel(GemmArgs g) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* xs = smem;                              // [135][36]  rows m0 - pad .. m0 + 127 + 7 - pad
+    float* ws = smem + (C32_ROWS + 7) * XS_LD;     // [32][260]  weights of columns n0 .. n0 + 31, k-contiguous
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, i = lane & 31, h = lane >> 5;
+    const int m0 = blockIdx.x * C32_ROWS, n0 = blockIdx.y * 32, pad = g.convPad, L = g.convL;
+    for (int c = tid; c < (C32_ROWS + 7) * 8; c += NTHREADS) {
+        const int r = c >> 3, q = c & 7;
+        const long src = (long)m0 - pad + r;
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (src >= 0 && src < g.M) v = *reinterpret_cast<const float4*>(g.A + src * C32 + 4 * q);
+        *reinterpret_cast<float4*>(xs + r * XS_LD + 4 * q) = v;
+    }
+    for (int c = tid; c < 32 * 64; c += NTHREADS) {
+        const int r = c >> 6, q = c & 63;
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (n0 + r < g.N) v = *reinterpret_cast<const float4*>(g.B + (long)(n0 + r) * (8 * C32) + 4 * q);
+        *reinterpret_cast<float4*>(ws + r * WS_LD + 4 * q) = v;
+    }
+    __syncthreads();
+
+    const int mrow = m0 + wave * 32 + i;           // the output row whose A values this lane feeds
+    const int l = mrow < g.M ? mrow % L : -(1 << 20);
+    f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+#pragma unroll
+    for (int t = 0; t < 8; ++t) {
+        const bool ok = (unsigned)(l + t - pad) < (unsigned)L;
+        const float* ap = xs + (wave * 32 + i + t) * XS_LD + 4 * h;
+        const float* bp = ws + i * WS_LD + t * C32 + 4 * h;
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) {
+            f32x4 a = *reinterpret_cast<const f32x4*>(ap + 8 * kk);
+            const f32x4 b = *reinterpret_cast<const f32x4*>(bp + 8 * kk);
+            if (!ok) { a[0] = 0.f; a[1] = 0.f; a[2] = 0.f; a[3] = 0.f; }
+#pragma unroll
+            for (int s2 = 0; s2 < 4; ++s2) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[s2], b[s2], acc, 0, 0, 0);
+        }
+    }
+    const int col = n0 + i;
+    if (col < g.N) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int row = m0 + wave * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+            if (row < g.M) {
+                if constexpr (EPI) g.P[(long)row * g.ldp + col] = epi_apply(g, acc[r], row, col);
+                else g.P[(long)row * g.ldp + col] = acc[r];
+            }
+        }
+    }
+}
+
+template <bool EPI>
+int launch_conv8_c32(const GemmArgs& g, hipStream_t st) {
+    static bool attr = false;
+    const size_t lds = (size_t)C32_LDS_FLOATS * sizeof(float);
+    if (!attr) {
+        (void)hipFuncSetAttribute((const void*)conv8_c32_kernel<EPI>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        attr = true;
+    }
+    hipLaunchKernelGGL((conv8_c32_kernel<EPI>), dim3(cdiv(g.M, C32_ROWS), cdiv(g.N, 32)), dim3(NTHREADS), lds, st, g);
+    WFD_CHECK_LAUNCH();
+    return WFD_OK;
+}
+
+// the LDS-resident form pays when there are enough 128-row tiles to fill the chip
+inline bool use_conv8_c32(int M, int Cin, int Cout) { return Cin == C32 && (long)cdiv(M, C32_ROWS) * cdiv(Cout, 32) >= 128; }
+
 template <bool AKC, bool BKC, bool IM2COL>
 int launch_gemm(const GemmArgs& g, int splits, bool va4, bool vb4, hipStream_t st) {
     if (g.narrow) {
@@ -305,6 +385,10 @@ int wfd_gemm_pick_splits(int M, int N, int K) {
     while (s > 1 && ktiles / s < 2) --s;
     return s;
 }
+
+// 1 when the fused conv entry points run a (Bn*L, Cin, Cout) conv with the LDS-resident kernel (no K split needed: the
+// caller should take the fused single-launch path whatever wfd_gemm_pick_splits says)
+int wfd_conv8_direct(int M, int Cin, int Cout) { return use_conv8_c32(M, Cin, Cout) ? 1 : 0; }
 
 // layout: 0 = NT, 1 = NN, 2 = TN.  P receives `splits` slabs of M x ldp floats, slab_stride floats apart.
 int wfd_gemm_f32(int layout, const float* A, int lda, const float* B, int ldb, float* P, int ldp, long slab_stride,
@@ -341,6 +425,7 @@ int wfd_conv8_gemm_f32(const float* X, int Bn, int L, int Cin, int pad, const fl
     g.convL = L; g.convCin = Cin; g.convPad = pad;
     g.narrow = Cout <= 32;
     if (splits > 1 && slab_stride < (long)g.M * ldp) return WFD_ERR_ARG;
+    if (splits == 1 && use_conv8_c32(g.M, Cin, Cout)) return launch_conv8_c32<false>(g, (hipStream_t)stream);
     return launch_gemm<true, true, true>(g, splits, true, true, (hipStream_t)stream);
 }
 
@@ -378,6 +463,7 @@ int wfd_conv8_gemm_f32_fused(const float* X, int Bn, int L, int Cin, int pad, co
     g.convL = L; g.convCin = Cin; g.convPad = pad;
     g.narrow = Cout <= 32;
     g.epi = epi; g.act = act; g.dmode = dmode; g.ldd = ldd; g.scale = scale; g.shift = shift; g.D = D;
+    if (use_conv8_c32(g.M, Cin, Cout)) return launch_conv8_c32<true>(g, (hipStream_t)stream);
     return launch_gemm<true, true, true>(g, 1, true, true, (hipStream_t)stream);
 }
 

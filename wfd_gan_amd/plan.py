@@ -182,14 +182,14 @@ class Plan:
             self.mul(self.gemm(layout, A, lda, B, ldb, M, N, K), D, ldd, dmode, colscale, None, out, None, ldo)
 
     def conv8_affine(self, X, Bn, L, Cin, pad, Wp, Cout, scale, shift, act, out):
-        if self.L.gemm_pick_splits(Bn * L, Cout, 8 * Cin) == 1:
+        if self.L.gemm_pick_splits(Bn * L, Cout, 8 * Cin) == 1 or self.L.conv8_direct(Bn * L, Cin, Cout):
             self.add(self.L.conv8_gemm_f32_fused, ptr(X), Bn, L, Cin, pad, ptr(Wp), Cout, ptr(out), Cout, 1, ptr(scale),
                      ptr(shift), act, 0, 0, 0)
         else:
             self.affine_act(self.conv8(X, Bn, L, Cin, pad, Wp, Cout), scale, shift, act, out, Cout)
 
     def conv8_mul(self, X, Bn, L, Cin, pad, Wp, Cout, D, ldd, dmode, colscale, out):
-        if self.L.gemm_pick_splits(Bn * L, Cout, 8 * Cin) == 1:
+        if self.L.gemm_pick_splits(Bn * L, Cout, 8 * Cin) == 1 or self.L.conv8_direct(Bn * L, Cin, Cout):
             self.add(self.L.conv8_gemm_f32_fused, ptr(X), Bn, L, Cin, pad, ptr(Wp), Cout, ptr(out), Cout, 2,
                      ptr(colscale), 0, 0, ptr(D), ldd, dmode)
         else:
