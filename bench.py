@@ -75,6 +75,13 @@ def run_steps(eng, start, n):
     """n iterations from iteration index `start`; whole groups of n_critic iterations go out as one graph replay
     where the engine offers it (re-permutes by itself at epoch ends)."""
     i, end = start, start + n
+    if hasattr(eng, "run_group"):               # GroupedTrainer: whole groups of n_critic iterations (D D D G)
+        nc = eng.n
+        for _ in range(n // nc):
+            eng.run_group()
+        for k in range(n % nc):                 # a K that is no multiple of n_critic: the rest on the plain engine
+            eng.base.iteration(start + (n // nc) * nc + k)
+        return
     group = getattr(eng, "iteration_group", None)
     nc = getattr(eng, "n_critic", 3)
     while i < end:
@@ -189,6 +196,9 @@ def main():
     ap.add_argument("--dp", default="weak", choices=["weak", "strong"],
                     help="N > 1: weak = --batch rows per GPU (DDP semantics, the driver's scaling runs); strong = --batch "
                          "rows split over the GPUs with SyncBN (result-equal to one GPU)")
+    ap.add_argument("--grouped", type=int, default=1,
+                    help="1: wfd_gan_amd.engine.GroupedTrainer (stacked generator forwards per group of n_critic "
+                         "iterations); 0: one iteration at a time")
     ap.add_argument("--pipeline", type=int, default=0,
                     help="1: software-pipelined driver (wfd_gan_amd.engine.PipelinedTrainer; measured 3 %% slower than "
                          "the sequential engine on one MI355X, see DESIGN.md section 6); 0: sequential engine")
@@ -207,7 +217,13 @@ def main():
     eng, (dmin, dmax) = build_engine(args, rank, world, device)
     strong = args.dp == "strong" and world > 1
     pipelined = bool(args.pipeline) and not strong
-    if pipelined:           # generator forward of iteration i+1 on a second stream beside iteration i's critic update
+    grouped = bool(args.grouped) and not strong and not pipelined
+    if grouped:             # the generator forwards of the n_critic iterations sharing generator parameters run stacked
+        from wfd_gan_amd.engine import GroupedTrainer
+        drv = GroupedTrainer(eng, graphs=not args.no_graph)
+        if not args.no_graph and args.steps % eng.n_critic:
+            eng.capture_graphs()
+    elif pipelined:         # generator forward of iteration i+1 on a second stream beside iteration i's critic update
         from wfd_gan_amd.engine import PipelinedTrainer
         drv = PipelinedTrainer(eng, graphs=not args.no_graph)
     else:
@@ -287,7 +303,8 @@ def main():
                                    f"penalty={args.penalty} ({'W-div k=2 p=6, what the reference runs' if args.penalty == 'div' else 'WGAN-GP interpolate'})",
                        "global_batch": eng.B * world, "optimizer_steps_per_s": steps_per_s,
                        "samples_per_s": steps_per_s * eng.B * world,
-                       "parallelism": f"dp{world}", "graphs": not args.no_graph, "pipelined": pipelined},
+                       "parallelism": f"dp{world}", "graphs": not args.no_graph, "pipelined": pipelined,
+                       "grouped_generator_forwards": grouped},
             "roofline": {"bound": "mfma", "achieved": roof["tflops"], "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
                          "frac": roof["tflops"] / PEAK_F32_MFMA_TFLOPS, "traffic": traffic,
                          "traffic_note": "bytes/launch, rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command "

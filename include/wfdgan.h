@@ -231,6 +231,25 @@ int wfd_sample_post(const float* Y, int ldy, int M, int S, const double* min_, c
 int wfd_sample_post_mode(const float* Y, int ldy, int M, int S, const double* min_, const double* scale_, int mode, int* out,
                          int ldo, int* len_out, void* stream);
 
+/* ---- stacked generator forwards (the heads of the iterations that share generator parameters run as ONE pass over
+ *      slots * B rows; no counterpart in the reference, which runs them one by one: src/mlp_df_wgan_train.py:196) ---- */
+
+/* wfd_gather_batch for `slots` consecutive batches: slot s reads the permutation slot_idx_stride entries after slot
+ * s - 1, writes real / fake rows at real + s * slot_stride (floats), generator input and labels stacked contiguously */
+int wfd_gather_batch_slots(const float* X, int ldX, const int* y, const long long* idx, const unsigned long long* state,
+                           long n_idx, long n_rows, long row_offset, int B, int slots, long slot_idx_stride, int S, int C,
+                           float* real, float* fake, int ldd, long slot_stride, float* zin, int ldz, int Z,
+                           int* labels_out, void* stream);
+/* wfd_bn_train_relu on `groups` independent batches of M rows stacked along the rows (statistics [groups][N]); the
+ * running statistics take one update per group, in order, exactly as successive forward calls would leave them */
+int wfd_bn_train_relu_grouped(const float* P, int ns, long ss, int ldp, int M, int groups, int N, const float* bias,
+                              float eps, const float* gamma, const float* beta, float* XH, float* H, int ldo, float* mean,
+                              float* m2, float* invstd, float* rmean, float* rvar, float momentum, void* stream);
+/* wfd_ep_sigmoid_lenmask whose output rows go to `out + slot * slot_stride` (slot = row / rows_per_slot) */
+int wfd_ep_sigmoid_lenmask_slots(const float* P, int ns, long ss, int ldp, int M, int S, const float* bias, float range,
+                                 float smin, float* out, int ldo, int rows_per_slot, long slot_stride, int* idx, int* err,
+                                 void* stream);
+
 /* ---- DF observer training (src/train_df.py:111-131 around src/model.py:135-206 in train mode) ---------------------- */
 
 /* weight gradient of the k=8 "SAME" conv (autograd of MyConv1dPadSame, src/model.py:91-104):

@@ -114,3 +114,81 @@ def test_group_graph_equals_single_iterations():
         outs.append((eng.Dp.flat.clone(), eng.Gp.flat.clone(), dict(eng.nbt), eng.iter_state.clone()))
     assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
     assert outs[0][2] == outs[1][2] and torch.equal(outs[0][3], outs[1][3])
+
+
+@pytest.mark.parametrize("penalty", ["div", "gp"])
+def test_grouped_heads_equal_sequential_replay(penalty):
+    """GroupedTrainer: the generator forwards of the three iterations of a group run stacked (3*B rows, BatchNorm per
+    batch).  Every iteration of two groups is replayed on a sequential engine from the same parameters with the
+    batch / z / masks the grouped run used.  Not bit-identical (a 3*B-row GEMM splits K differently), so: generated
+    rows to 1e-5, updated parameters to 1e-5 of their scale, BatchNorm running statistics to 1e-5."""
+    from wfd_gan_amd.engine import GroupedTrainer
+    S, C, Z, B = 101, 6, 24, 16
+    X, y = O.synth_dataset(C, 30, S - 1, 10, 13, 122, seed=1)
+    dmin, dmax = X.min(0), X.max(0)
+    scale, min_ = O.scaler_params(dmin, dmax)
+    Xs = torch.from_numpy(X * scale + min_).float()
+    st = O.make_state(S, C, Z, dmin[0], dmax[0], seed=2, df_seed=3)
+    O.perturb_df_bn(st.DF, 4)
+    eng = _engine(S, C, Z, B, st, penalty=penalty, seed=11)
+    eng.attach_dataset(Xs, torch.from_numpy(y), shuffle_seed=5)
+    grp = GroupedTrainer(eng, graphs=False)
+    ref = _engine(S, C, Z, B, st, penalty=penalty)
+    perm = eng.perm.clone()
+    for gi in range(2):
+        bn0 = {k: v.clone() for k, v in eng.Gbuf.items()}
+        for k, v in bn0.items():
+            ref.Gbuf[k].copy_(v)
+        grp.head.run()
+        torch.cuda.synchronize()
+        for k in range(3):
+            s = grp.slot(k)
+            # the stacked gather took batch 3*gi + k of the permutation
+            want_idx = perm[(3 * gi + k) * B:(3 * gi + k + 1) * B]
+            assert torch.equal(s.buf["labels"].long(), eng.data_y[want_idx].long())
+            assert torch.equal(s.real_rows[:, :S], eng.data_X[want_idx])
+            pre = dict(G=eng.Gp.flat.clone(), Gsq=eng.Gp.sq.clone(), D=eng.Dp.flat.clone(), Dsq=eng.Dp.sq.clone())
+            grp.rest[k].run()
+            if k == 2:
+                grp.gstep.run()
+            torch.cuda.synchronize()
+            ref.Gp.flat.copy_(pre["G"]); ref.Gp.sq.copy_(pre["Gsq"]); ref.Dp.flat.copy_(pre["D"]); ref.Dp.sq.copy_(pre["Dsq"])
+            ref.set_batch(s.real_rows[:, :S], s.buf["labels"], s.buf["ZIN"][:, :Z])
+            if penalty == "gp":
+                ref.set_gp_alpha(s.buf["GPA"])
+            ref.set_masks([s.buf[f"MK{j}"] for j in (1, 2, 3)], [s.buf[f"gMK{j}"] for j in (1, 2, 3)] if k == 2 else None)
+            ref.d_step()
+            if k == 2:
+                ref.g_step()
+            torch.cuda.synchronize()
+            assert float((ref.fake_rows - s.fake_rows).abs().max()) < 1e-5, f"group {gi} slot {k}: generated rows"
+            assert torch.equal(ref.buf["idx"], s.buf["idx"])
+            for a, bb, what in ((ref.Dp.flat, eng.Dp.flat, "critic"), (ref.Gp.flat, eng.Gp.flat, "generator")):
+                assert float((a - bb).abs().max()) <= 1e-5 * float(a.abs().max()), f"group {gi} slot {k}: {what}"
+        for k, v in eng.Gbuf.items():       # 3 forward updates + the G-step's, in order
+            assert float((ref.Gbuf[k] - v).abs().max()) <= 1e-5 * max(1.0, float(v.abs().max())), k
+    assert not int(eng.buf["err"].item())
+
+
+def test_grouped_graph_equals_eager():
+    from wfd_gan_amd.engine import GroupedTrainer
+    S, C, Z, B = 61, 4, 16, 8
+    X, y = O.synth_dataset(C, 20, S - 1, 10, 13, 122, seed=1)          # 80 rows: 10 iterations per epoch
+    dmin, dmax = X.min(0), X.max(0)
+    scale, min_ = O.scaler_params(dmin, dmax)
+    Xs = torch.from_numpy(X * scale + min_).float()
+    outs = []
+    for graphs in (False, True):
+        st = O.make_state(S, C, Z, dmin[0], dmax[0], seed=2, df_seed=3)
+        eng = _engine(S, C, Z, B, st, seed=3)
+        eng.attach_dataset(Xs, torch.from_numpy(y), shuffle_seed=5)
+        grp = GroupedTrainer(eng, graphs=graphs)
+        for _ in range(7):                                              # crosses epoch boundaries
+            assert grp.run_group() == 3
+        torch.cuda.synchronize()
+        outs.append((eng.Dp.flat.clone(), eng.Gp.flat.clone(), {k: v.clone() for k, v in eng.Gbuf.items()}, dict(eng.nbt)))
+    assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
+    for k in outs[0][2]:
+        assert torch.equal(outs[0][2][k], outs[1][2][k]), k
+    assert outs[0][3] == outs[1][3] and outs[0][3]["model.3"] == 28
+    assert torch.isfinite(outs[0][0]).all() and torch.isfinite(outs[0][1]).all()

@@ -451,6 +451,11 @@ __global__ __launch_bounds__(CTS * RG) void bn_train_relu_small_kernel(
     float* __restrict__ rmean, float* __restrict__ rvar, float momentum, int nupd) {
     __shared__ float red[RG][CTS];
     const int n = blockIdx.x * CTS + threadIdx.x, rg = threadIdx.y;
+    // blockIdx.y = row group (batched generator forwards: each group of M rows is its own BatchNorm batch)
+    P += (long)blockIdx.y * M * ldp;
+    XH += (long)blockIdx.y * M * ldo;
+    H += (long)blockIdx.y * M * ldo;
+    mean += (long)blockIdx.y * N; m2 += (long)blockIdx.y * N; invstd_out += (long)blockIdx.y * N;
     const bool ok = n < N;
     const float b = ok && bias ? bias[n] : 0.f;
     float z[RPT];
@@ -535,14 +540,16 @@ __global__ void bn_apply_relu_kernel(const float* __restrict__ Z, int ldz, int M
 
 __global__ void bn_running_update_kernel(const float* __restrict__ mean, const float* __restrict__ m2, float count,
                                          int N, float* __restrict__ rmean, float* __restrict__ rvar, float momentum,
-                                         int nupd) {
+                                         int nupd, int groups) {
     const int n = blockIdx.x * blockDim.x + threadIdx.x;
     if (n >= N) return;
-    const float mu = mean[n], uv = m2[n] / (count - 1.f);
     float rm = rmean[n], rv = rvar[n];
-    for (int u = 0; u < nupd; ++u) {
-        rm = (1.f - momentum) * rm + momentum * mu;
-        rv = (1.f - momentum) * rv + momentum * uv;
+    for (int g = 0; g < groups; ++g) {          // the groups' batches in order, as successive forward calls would
+        const float mu = mean[(long)g * N + n], uv = m2[(long)g * N + n] / (count - 1.f);
+        for (int u = 0; u < nupd; ++u) {
+            rm = (1.f - momentum) * rm + momentum * mu;
+            rv = (1.f - momentum) * rv + momentum * uv;
+        }
     }
     rmean[n] = rm;
     rvar[n] = rv;
@@ -642,8 +649,10 @@ __global__ __launch_bounds__(CTS * RG) void bn_bwd_small_kernel(
 __global__ void ep_sigmoid_lenmask_kernel(const float* __restrict__ P, int ns, long ss, int ldp, int S,
                                           const float* __restrict__ bias, float range, float smin,
                                           float* __restrict__ out, int ldo, int* __restrict__ idx_out,
-                                          int* __restrict__ err) {
+                                          int* __restrict__ err, int rows_per_slot, long slot_stride) {
     const int m = blockIdx.x;
+    // output rows of slot s = m / rows_per_slot start slot_stride floats after those of slot s - 1
+    if (rows_per_slot > 0) out += (long)(m / rows_per_slot) * slot_stride - (long)(m / rows_per_slot) * rows_per_slot * ldo;
     const float y0 = 1.0f / (1.0f + expf(-(slab_sum(P, ns, ss, (long)m * ldp) + bias[0])));
     const float bl = __fadd_rn(__fmul_rn(y0, range), smin);
     long idx = (long)bl + 1;
@@ -878,8 +887,35 @@ int wfd_bn_running_update(const float* mean, const float* m2, float count, int N
                           float momentum, int nupd, void* stream) {
     if (!mean || !m2 || !rmean || !rvar) return WFD_ERR_ARG;
     hipLaunchKernelGGL(bn_running_update_kernel, dim3(cdiv(N, 256)), dim3(256), 0, (hipStream_t)stream, mean, m2, count,
-                       N, rmean, rvar, momentum, nupd);
+                       N, rmean, rvar, momentum, nupd, 1);
     WFD_CHECK_LAUNCH();
+    return WFD_OK;
+}
+
+// Batched generator forwards: `groups` independent BatchNorm batches of M rows each, stacked along the rows of P
+// (the heads of the iterations that share generator parameters).  Statistics go to mean / m2 / invstd [groups][N];
+// the running statistics are then updated once per group, in order.
+int wfd_bn_train_relu_grouped(const float* P, int ns, long ss, int ldp, int M, int groups, int N, const float* bias,
+                              float eps, const float* gamma, const float* beta, float* XH, float* H, int ldo, float* mean,
+                              float* m2, float* invstd, float* rmean, float* rvar, float momentum, void* stream) {
+    if (!P || !gamma || !beta || !XH || !H || !mean || !m2 || !invstd || M < 2 || groups < 1 || M > RG * 8)
+        return WFD_ERR_ARG;
+    constexpr int CTS = 8;
+    hipStream_t st = (hipStream_t)stream;
+    if (M <= RG * 4)
+        hipLaunchKernelGGL((bn_train_relu_small_kernel<CTS, 4>), dim3(cdiv(N, CTS), groups), dim3(CTS, RG), 0, st, P, ns, ss,
+                           ldp, M, N, bias, eps, gamma, beta, XH, H, ldo, mean, m2, invstd, (float*)nullptr,
+                           (float*)nullptr, momentum, 0);
+    else
+        hipLaunchKernelGGL((bn_train_relu_small_kernel<CTS, 8>), dim3(cdiv(N, CTS), groups), dim3(CTS, RG), 0, st, P, ns, ss,
+                           ldp, M, N, bias, eps, gamma, beta, XH, H, ldo, mean, m2, invstd, (float*)nullptr,
+                           (float*)nullptr, momentum, 0);
+    WFD_CHECK_LAUNCH();
+    if (rmean) {
+        hipLaunchKernelGGL(bn_running_update_kernel, dim3(cdiv(N, 256)), dim3(256), 0, st, mean, m2, (float)M, N, rmean,
+                           rvar, momentum, 1, groups);
+        WFD_CHECK_LAUNCH();
+    }
     return WFD_OK;
 }
 
@@ -909,7 +945,18 @@ int wfd_ep_sigmoid_lenmask(const float* P, int ns, long ss, int ldp, int M, int 
                            float smin, float* out, int ldo, int* idx, int* err, void* stream) {
     if (!P || !bias || !out || !idx || !err) return WFD_ERR_ARG;
     hipLaunchKernelGGL(ep_sigmoid_lenmask_kernel, dim3(M), dim3(512), 0, (hipStream_t)stream, P, ns, ss, ldp, S, bias,
-                       range, smin, out, ldo, idx, err);
+                       range, smin, out, ldo, idx, err, 0, 0l);
+    WFD_CHECK_LAUNCH();
+    return WFD_OK;
+}
+
+// the same for stacked generator forwards: rows [s*rows_per_slot, (s+1)*rows_per_slot) go to out + s*slot_stride
+int wfd_ep_sigmoid_lenmask_slots(const float* P, int ns, long ss, int ldp, int M, int S, const float* bias, float range,
+                                 float smin, float* out, int ldo, int rows_per_slot, long slot_stride, int* idx, int* err,
+                                 void* stream) {
+    if (!P || !bias || !out || !idx || !err || rows_per_slot <= 0 || M % rows_per_slot) return WFD_ERR_ARG;
+    hipLaunchKernelGGL(ep_sigmoid_lenmask_kernel, dim3(M), dim3(512), 0, (hipStream_t)stream, P, ns, ss, ldp, S, bias,
+                       range, smin, out, ldo, idx, err, rows_per_slot, slot_stride);
     WFD_CHECK_LAUNCH();
     return WFD_OK;
 }

@@ -66,11 +66,25 @@ __global__ void gather_batch_kernel(const float* __restrict__ X, int ldX, const 
                                     const long long* __restrict__ idx, const unsigned long long* __restrict__ state,
                                     long n_idx, long n_rows, long row_offset, int S, int C, float* __restrict__ real,
                                     float* __restrict__ fake, int ldd, float* __restrict__ zin, int ldz, int Z,
-                                    int* __restrict__ labels_out) {
-    const int b = blockIdx.x;
+                                    int* __restrict__ labels_out, int rows_per_slot, long slot_stride,
+                                    long slot_idx_stride) {
+    int b = blockIdx.x;
+    long pos = row_offset + b;
+    if (rows_per_slot > 0) {
+        // stacked batches of several iterations: slot s = b / rows_per_slot reads the permutation slot_idx_stride
+        // entries further on (= the rows all ranks consume per iteration) and writes its own real / fake buffers;
+        // the generator input and the labels are stacked contiguously
+        const int slot = b / rows_per_slot, r = b - slot * rows_per_slot;
+        pos = row_offset + (long)slot * slot_idx_stride + r;
+        real += (long)slot * slot_stride;
+        if (fake) fake += (long)slot * slot_stride;
+        if (zin) zin += (long)slot * rows_per_slot * ldz;
+        if (labels_out) labels_out += slot * rows_per_slot;
+        b = r;
+    }
     // the cursor wraps inside the permutation and the row index is clamped: a stale cursor can never make
     // this kernel read outside the dataset
-    long long src = idx[((state ? (long long)state[1] : 0ll) + row_offset + b) % n_idx];
+    long long src = idx[((state ? (long long)state[1] : 0ll) + pos) % n_idx];
     src = src < 0 ? 0 : (src >= n_rows ? n_rows - 1 : src);
     const int lab = y[src];
     for (int j = threadIdx.x; j < S; j += blockDim.x) real[(long)b * ldd + j] = X[src * ldX + j];
@@ -299,7 +313,18 @@ int wfd_gather_batch(const float* X, int ldX, const int* y, const long long* idx
                      float* zin, int ldz, int Z, int* labels_out, void* stream) {
     if (!X || !y || !idx || !real || B <= 0 || n_idx <= 0 || n_rows <= 0 || row_offset < 0) return WFD_ERR_ARG;
     hipLaunchKernelGGL(gather_batch_kernel, dim3(B), dim3(256), 0, (hipStream_t)stream, X, ldX, y, idx, state, n_idx, n_rows,
-                       row_offset, S, C, real, fake, ldd, zin, ldz, Z, labels_out);
+                       row_offset, S, C, real, fake, ldd, zin, ldz, Z, labels_out, 0, 0l, 0l);
+    WFD_CHECK_LAUNCH();
+    return WFD_OK;
+}
+
+int wfd_gather_batch_slots(const float* X, int ldX, const int* y, const long long* idx, const unsigned long long* state,
+                           long n_idx, long n_rows, long row_offset, int B, int slots, long slot_idx_stride, int S, int C,
+                           float* real, float* fake, int ldd, long slot_stride, float* zin, int ldz, int Z,
+                           int* labels_out, void* stream) {
+    if (!X || !y || !idx || !real || B <= 0 || slots <= 0 || n_idx <= 0 || n_rows <= 0 || row_offset < 0) return WFD_ERR_ARG;
+    hipLaunchKernelGGL(gather_batch_kernel, dim3(B * slots), dim3(256), 0, (hipStream_t)stream, X, ldX, y, idx, state, n_idx,
+                       n_rows, row_offset, S, C, real, fake, ldd, zin, ldz, Z, labels_out, B, slot_stride, slot_idx_stride);
     WFD_CHECK_LAUNCH();
     return WFD_OK;
 }

@@ -165,7 +165,8 @@ class TrainEngine:
                  penalty: str = "div", lambda_gp: float = 10.0, device="cuda:0", global_batch: Optional[int] = None,
                  seed: int = 0, workspace_mb: int = 256, process_group=None, world_size: int = 1,
                  share: Optional["TrainEngine"] = None, overlap: bool = False, force_sync: bool = False,
-                 sync_bn: bool = False, rank: int = 0):
+                 sync_bn: bool = False, rank: int = 0, stacked: Optional[Dict[str, torch.Tensor]] = None,
+                 slot: int = 0):
         """Data parallel, two modes:
           * sync_bn=False (weak scaling, DDP semantics): every rank trains on its own ``batch`` rows with local
             BatchNorm statistics and a local selected-row count; gradients are averaged over ranks.
@@ -279,6 +280,12 @@ class TrainEngine:
         b["ws"] = torch.empty(max(workspace_mb * (1 << 18), B * S * 64), **f32)
         b["ws2"] = torch.empty(64 * (1 << 18), **f32)        # slab workspace of the side lane
         b["ws_gf"] = torch.empty(max(16 * B * 2048, 1 << 20), **f32)   # slabs of a generator forward running ahead
+        if stacked is not None:
+            # GroupedTrainer: this engine is one slot of a stack; the buffers the batched generator forward writes are
+            # views of tensors shaped [slots, ...]
+            for nme, t in stacked.items():
+                assert tuple(t[slot].shape) == tuple(b[nme].shape), nme
+                b[nme] = t[slot]
         self.overlap = overlap
 
         # [philox counter, perm cursor] of the step plans; gf_state: the same pair for the stand-alone generator-forward
@@ -407,7 +414,16 @@ class TrainEngine:
         B, M, S, C, Z, b, D = self.B, self.M, self.S, self.C, self.Z, self.buf, self.Dp
         p = Plan(b["ws"] if part != "gf" else b["ws_gf"], b["ws2"], self.overlap)
         st = self.iter_state.data_ptr() if part != "gf" else self.gf_state.data_ptr()
-        if part == "rest":
+        if part in ("rest", "rest_draw"):
+            if part == "rest_draw":
+                # the head ran stacked with other iterations' heads (GroupedTrainer) and drew only z: the dropout masks
+                # (and the WGAN-GP interpolates) of this iteration are produced here
+                t = b["MKflat"]
+                p.add(self.L.rng_dropout_mask, ptr(t), t.numel(), 0.2, (self.seed + self.GOLD) & (2**64 - 1), st, 0)
+                if self.penalty == "gp":
+                    p.add(self.L.rng_uniform, ptr(b["GPA"]), B, (self.seed + 11 * self.GOLD) & (2**64 - 1), st, 0)
+                    p.add(self.L.interpolate_rows, ptr(self.real_rows), ptr(self.fake_rows), ptr(b["GPA"]),
+                          ptr(self.din[2 * B:]), B, S, S + C, self.ldx)
             return self._build_d_rest(p, fast, own_cursor=False)
         if fast:
             p.add(self.L.gather_batch, ptr(self.data_X), S, ptr(self.data_y), ptr(self.perm), st, self.N, self.N,
@@ -984,3 +1000,132 @@ class PipelinedTrainer:
     def check_length_index(self):
         for e in self.e:
             e.check_length_index()
+
+
+STACKED_NAMES = ("XC", "ZIN", "labels", "idx", "GH1", "GXH2", "GH2", "GXH3", "GH3", "mean2", "m22", "istd2", "mean3",
+                 "m23", "istd3")
+
+
+class GroupedTrainer:
+    """Fast-mode driver that runs the generator forwards of the n_critic iterations that share generator parameters
+    as ONE stacked pass.
+
+    The generator changes only in G-steps (every n_critic-th iteration, after that iteration's D-step).  With
+    n_critic = 3 the reference's schedule is  D0 G0 | D1 D2 D3 G3 | D4 D5 D6 G6 | ...: inside a group the three
+    D-steps see the same generator, and their heads (batch gather, z draw, generator forward: nothing a critic update
+    writes) depend on nothing but it.  So a group runs as
+
+        head(3 batches stacked: one gather, one z draw, four GEMMs over 3*B rows, BatchNorm per 64-row batch,
+             running statistics updated once per batch in order)
+        rest(i) rest(i+1) rest(i+2)  G-step(i+2)
+
+    i.e. 12 launches for the three heads instead of 33, on GEMMs three times as tall (the B = 64
+    step is launch/latency-bound).  Each iteration keeps its own buffers ("slot" engines on shared parameters whose
+    head buffers are views of the stacked tensors), so the critic update, the penalty and the G-step are the
+    sequential engine's plans unchanged; arithmetic and the order of every state update are the reference's."""
+
+    def __init__(self, eng: "TrainEngine", graphs: bool = True):
+        if eng.exact:
+            raise ValueError("the grouped driver does not cover the SyncBN mode (collectives inside the generator forward)")
+        if not hasattr(eng, "data_X"):
+            raise RuntimeError("attach_dataset() first")
+        if eng.B > 128:
+            raise ValueError("stacked BatchNorm kernel covers batches up to 128 rows")
+        n = self.n = eng.n_critic
+        dev = eng.dev
+        self.stacked = {k: torch.zeros((n,) + tuple(eng.buf[k].shape), dtype=eng.buf[k].dtype, device=dev)
+                        for k in STACKED_NAMES}
+        self.e = [TrainEngine(eng.S, eng.C, eng.Z, eng.B, eng.scaler_min, eng.scaler_max, {}, {}, {}, lr=eng.lr,
+                              alpha=eng.alpha, n_critic=n, penalty=eng.penalty, lambda_gp=eng.lambda_gp, device=dev,
+                              seed=eng.seed + 0x9E37 * (k + 1), process_group=eng.pg, world_size=eng.world, share=eng,
+                              rank=eng.rank, stacked=self.stacked, slot=k) for k in range(n)]
+        self.base = eng
+        for e in self.e:
+            for name in ("data_X", "data_y", "N", "perm", "perm_gen", "iters_per_epoch"):
+                setattr(e, name, getattr(eng, name))
+        eng.gf_state.zero_()
+        self.ws = torch.empty(max(16 * n * eng.B * 2048, 1 << 20), dtype=torch.float32, device=dev)
+        self.head = self._build_head()
+        self.rest = [e._build_d_plan(fast=True, part="rest_draw") for e in self.e]
+        self.gstep = self.e[n - 1]._build_g_plan(fast=True)
+        self.group = Plan(self.ws)
+        self.group.extend(self.head)
+        for r in self.rest:
+            self.group.extend(r)
+        self.group.extend(self.gstep)
+        self._pos = 0
+        self.auto_reshuffle = True
+        self.stages = None
+        if graphs:
+            self._capture()
+
+    def _build_head(self) -> Plan:
+        eng, n, L = self.base, self.n, self.base.L
+        B, S, C, Z, G, st = eng.B, eng.S, eng.C, eng.Z, eng.Gp.p, self.stacked
+        M = n * B
+        p = Plan(self.ws)
+        state = eng.gf_state.data_ptr()
+        xc = st["XC"]                                   # [n][2*Mslot][ldx]
+        slot_stride = xc.stride(0)
+        real0, fake0 = self.e[0].real_rows, self.e[0].fake_rows
+        p.add(L.gather_batch_slots, ptr(eng.data_X), S, ptr(eng.data_y), ptr(eng.perm), state, eng.N, eng.N, eng.row_offset,
+              B, n, eng.cursor_step, S, C, ptr(real0), ptr(fake0), eng.ldx, slot_stride, ptr(st["ZIN"]), eng.ldz, Z,
+              ptr(st["labels"]))
+        p.add(L.rng_normal_rows, ptr(st["ZIN"]), eng.ldz, M, Z, (eng.seed + 7 * eng.GOLD) & (2**64 - 1), state, 0)
+        s = p.gemm(NT, st["ZIN"], eng.ldz, G["model.0.weight"], eng.Gp.ld["model.0.weight"], M, 512, Z + C)
+        p.affine_act(s, None, G["model.0.bias"], ACT_RELU, st["GH1"], 512)
+        prev, kprev = st["GH1"], 512
+        for i, lin, bn, width in ((2, "model.2", "model.3", 1024), (3, "model.5", "model.6", 2048)):
+            s = p.gemm(NT, prev, kprev, G[f"{lin}.weight"], kprev, M, width, kprev)
+            p.add(L.bn_train_relu_grouped, s.ptr, s.ns, s.ss, s.ldp, B, n, width, ptr(G[f"{lin}.bias"]), 0.8,
+                  ptr(G[f"{bn}.weight"]), ptr(G[f"{bn}.bias"]), ptr(st[f"GXH{i}"]), ptr(st[f"GH{i}"]), width,
+                  ptr(st[f"mean{i}"]), ptr(st[f"m2{i}"]), ptr(st[f"istd{i}"]), ptr(eng.Gbuf[f"{bn}.running_mean"]),
+                  ptr(eng.Gbuf[f"{bn}.running_var"]), 0.1)
+            prev, kprev = st[f"GH{i}"], width
+        s = p.gemm(NT, prev, 2048, G["model.8.weight"], 2048, M, S, 2048)
+        p.add(L.ep_sigmoid_lenmask_slots, s.ptr, s.ns, s.ss, s.ldp, M, S, ptr(G["model.8.bias"]), eng.range_f, eng.smin_f,
+              ptr(fake0), eng.ldx, B, slot_stride, ptr(st["idx"]), ptr(eng.buf["err"]))
+        p.add(L.iter_advance, state, (M * Z + 3) // 4, n * eng.cursor_step)
+        return p
+
+    def _capture(self):
+        eng = self.base
+        snap, gfs = eng._snapshot(), eng.gf_state.clone()
+        warm = torch.cuda.Stream(device=eng.dev)
+        warm.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(warm):
+            self.group.run()
+        torch.cuda.current_stream().wait_stream(warm)
+        torch.cuda.synchronize()
+        self.stages = TrainEngine._capture_stages(self.group)
+        torch.cuda.synchronize()
+        eng._restore(snap)
+        eng.gf_state.copy_(gfs)
+
+    def slot(self, k: int) -> "TrainEngine":
+        """Buffers of the k-th iteration of the last group (k = n_critic - 1: the one with the G-step)."""
+        return self.e[k]
+
+    def run_group(self) -> int:
+        """n_critic iterations: D D ... D G (the G-step belongs to the last one).  Returns n_critic."""
+        eng, n = self.base, self.n
+        if self.auto_reshuffle and self._pos + n > eng.iters_per_epoch:
+            self.reshuffle()                 # the remaining < n_critic batches of the permutation are skipped
+        if self.stages is not None:
+            for st in self.stages:
+                st()
+        else:
+            self.group.run()
+        eng.nbt["model.3"] += n + 1
+        eng.nbt["model.6"] += n + 1
+        self._pos += n
+        return n
+
+    def reshuffle(self):
+        eng = self.base
+        eng.perm.copy_(torch.randperm(eng.N, generator=eng.perm_gen, device=eng.dev))
+        eng.gf_state[1] = 0
+        self._pos = 0
+
+    def check_length_index(self):
+        self.base.check_length_index()
