@@ -92,7 +92,7 @@ def run_steps(eng, start, n):
             i += 1
 
 
-def gemm_roofline(eng, rep=16, rounds=3):
+def gemm_roofline(eng, plans=None, rep=16, rounds=3):
     """Live timing of the dominant kernel (the fp32 MFMA GEMM core, all its layouts) at the launches of one group of
     three iterations (3 D-steps + 1 G-step).  Every GEMM launch of the fast-mode plans is captured `rep` times
     back-to-back in a HIP graph of its own and the replay is bracketed by HIP events on the launch stream
@@ -105,7 +105,7 @@ def gemm_roofline(eng, rep=16, rounds=3):
     gemm_fns = {L.gemm_f32: "gemm", L.conv8_gemm_f32: "conv", L.gemm_f32_fused: "gemm_fused",
                 L.conv8_gemm_f32_fused: "conv"}
     calls = []
-    for plan, weight in ((eng.fast_d, eng.n_critic), (eng.fast_g, 1)):
+    for plan, weight in (plans or ((eng.fast_d, eng.n_critic), (eng.fast_g, 1))):
         for fn, a, _lane in plan.calls:
             if fn is FORK or fn is JOIN or fn is HOST:
                 continue
@@ -251,7 +251,8 @@ def main():
     # batch of --batch rows per step.
     its = steps_per_s * (1 if strong else world)
 
-    roof = gemm_roofline(eng)
+    # the launches of the plans that were timed above (one group of n_critic iterations either way)
+    roof = gemm_roofline(eng, [(drv.group, 1)] if grouped else None)
     traffic = None          # HBM bytes per GEMM launch from the committed PMC passes (tools/pmc_traffic.py)
     try:
         traffic = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))["_gemm_all"]["hbm_bytes_per_launch"]
@@ -309,7 +310,7 @@ def main():
                          "frac": roof["tflops"] / PEAK_F32_MFMA_TFLOPS, "traffic": traffic,
                          "traffic_note": "bytes/launch, rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command "
                                          "(profiles/pmc_traffic.json; FETCH x2 per MI355X_MICROARCH HBM section)",
-                         "kernel": "gemm_f32_kernel (fp32 MFMA core, all layouts)", "launches_timed": roof["launches"],
+                         "kernel": "fp32 MFMA core: gemm_f32_kernel (all layouts, implicit-GEMM conv) + conv8_c32_kernel", "launches_timed": roof["launches"],
                          "avg_flops_per_launch": roof["avg_flops"], "avg_us_per_launch": roof["avg_us"]},
         }
         if samp:

@@ -192,3 +192,39 @@ def test_grouped_graph_equals_eager():
         assert torch.equal(outs[0][2][k], outs[1][2][k]), k
     assert outs[0][3] == outs[1][3] and outs[0][3]["model.3"] == 28
     assert torch.isfinite(outs[0][0]).all() and torch.isfinite(outs[0][1]).all()
+
+
+def test_grouped_trainer_cursor_handover():
+    """The trainer's epoch schedule: iteration 0 on the plain engine, groups from batch 1 (cursor of the stacked heads
+    set by hand), the leftover full batches on the plain engine again -- every batch of the permutation exactly once."""
+    from wfd_gan_amd.engine import GroupedTrainer
+    S, C, Z, B = 61, 4, 16, 8
+    X, y = O.synth_dataset(C, 20, S - 1, 10, 13, 122, seed=1)          # 80 rows: 10 batches
+    dmin, dmax = X.min(0), X.max(0)
+    scale, min_ = O.scaler_params(dmin, dmax)
+    Xs = torch.from_numpy(X * scale + min_).float()
+    st = O.make_state(S, C, Z, dmin[0], dmax[0], seed=2, df_seed=3)
+    eng = _engine(S, C, Z, B, st, seed=3)
+    eng.attach_dataset(Xs, torch.from_numpy(y), shuffle_seed=5)
+    eng.auto_reshuffle = False
+    eng.capture_graphs()
+    grp = GroupedTrainer(eng, graphs=True)
+    grp.auto_reshuffle = False
+    perm = eng.perm.clone()
+    used = []
+    eng.iteration(0)
+    used.append(eng.real_rows[:, :S].clone())
+    eng.gf_state[1] = B
+    i = 1
+    while i + 3 <= 10:
+        grp.run_group()
+        used += [grp.slot(k).real_rows[:, :S].clone() for k in range(3)]
+        i += 3
+    eng.iter_state[1] = i * B
+    while i < 10:
+        eng.iteration(i)
+        used.append(eng.real_rows[:, :S].clone())
+        i += 1
+    torch.cuda.synchronize()
+    got = torch.cat(used)
+    assert torch.equal(got, eng.data_X[perm])

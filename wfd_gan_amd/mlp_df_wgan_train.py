@@ -29,7 +29,7 @@ from sklearn import preprocessing
 from . import common as cm
 from . import parallel, utils
 from ._lib import lib
-from .engine import TrainEngine
+from .engine import GroupedTrainer, TrainEngine
 from .model import DF, Discriminator, Generator
 
 w_dist_threshold = 0.05          # src/mlp_df_wgan_train.py:24
@@ -60,6 +60,9 @@ def parse_args(argv=None):
                    help="div = W-div (what the reference runs); gp = interpolated WGAN-GP (utils.py:64-84)")
     p.add_argument("--seed", type=int, default=None, help="seed for init / shuffling / device RNG")
     p.add_argument("--no_graph", action="store_true", help="launch kernels eagerly instead of HIP-graph replay")
+    p.add_argument("--no_group", action="store_true",
+                   help="one iteration per launch group (default: the generator forwards of the n_critic iterations "
+                        "that share generator parameters run as one stacked pass)")
     p.add_argument("--dp", choices=["strong", "weak"], default="strong",
                    help="torchrun launches only: strong = --batch_size is the global batch (SyncBN, result-equal to one "
                         "GPU); weak = --batch_size rows per GPU (local BatchNorm, averaged gradients)")
@@ -169,6 +172,11 @@ def main(argv=None):
     eng.auto_reshuffle = False        # the epoch loop below owns the permutation (ragged last batch)
     if not args.no_graph:
         eng.capture_graphs()
+    # iterations 1..3, 4..6, ... of an epoch (D D D G: same generator for the three D-steps) go out as groups
+    grp = None
+    if not exact and not args.no_group and args.n_critic >= 2 and B <= 128:
+        grp = GroupedTrainer(eng, graphs=not args.no_graph)
+        grp.auto_reshuffle = False
     n_full, tail_global = N // Bg, N % Bg
     tail_rows = tail_global // world
     tail = None
@@ -192,8 +200,23 @@ def main(argv=None):
         eng.buf["dacc"].zero_()
         eng.buf["gacc"].zero_()
         fill = 0
-        for i in range(n_batches):
-            do_g = (i % args.n_critic == 0)
+        i = 0
+        nc = args.n_critic
+        while i < n_batches:
+            if grp is not None and i % nc == 1 and i + nc <= n_full:
+                # iterations i .. i + nc - 1; the G-step belongs to the last one
+                if i == 1:
+                    eng.gf_state[1] = Bg                   # cursor of the stacked heads: batch 1 of this permutation
+                grp.run_group()
+                i += nc
+                j = i - 1
+                ep_fake[fill:fill + B].copy_(grp.slot(nc - 1).fake_rows[:, :seq_len])
+                ep_idx[fill:fill + B].copy_(eng.perm[j * Bg + rank * B: j * Bg + (rank + 1) * B])
+                fill += B
+                if i >= n_full or i + nc > n_full:
+                    eng.iter_state[1] = i * Bg             # the remaining full batches run one by one
+                continue
+            do_g = (i % nc == 0)
             if i < n_full:
                 eng.iteration(i)
                 src, rows, idx = eng, B, eng.perm[i * Bg + rank * B: i * Bg + (rank + 1) * B]
@@ -210,6 +233,7 @@ def main(argv=None):
                 ep_fake[fill:fill + rows].copy_(src.fake_rows[:, :seq_len])
                 ep_idx[fill:fill + rows].copy_(idx)
                 fill += rows
+            i += 1
         eng.reshuffle()
         eng.check_length_index()
         dacc, gacc = eng.epoch_sums()                     # the epoch's only host sync (and loss collective)
