@@ -10,7 +10,7 @@ import csv, glob, json, re, sys
 from collections import defaultdict
 
 def short(name):
-    m = re.search(r"(gemm_f32_kernel<[^>]*>|[A-Za-z0-9_]+_kernel)", name)
+    m = re.search(r"(gemm_f32_kernel<[^>]*>|conv8_c32_kernel<[^>]*>|[A-Za-z0-9_]+_kernel)", name)
     return m.group(1) if m else name[:60]
 
 def load(d, counter):
@@ -25,12 +25,12 @@ fetch, write = load(sys.argv[1], "FETCH_SIZE"), load(sys.argv[2], "WRITE_SIZE")
 res = {}
 for k in sorted(set(fetch) | set(write)):
     f, w = fetch.get(k, []), write.get(k, [])
-    if not (k.startswith("gemm") or k.endswith("_kernel")) or "at::" in k:
+    if not (k.startswith("gemm") or k.startswith("conv8_c32") or k.endswith("_kernel")) or "at::" in k:
         continue
     rd = 2.0 * 1024 * sum(f) / max(len(f), 1)
     wr = 1024.0 * sum(w) / max(len(w), 1)
     res[k] = dict(launches=len(f), read_bytes_per_launch=rd, write_bytes_per_launch=wr, hbm_bytes_per_launch=rd + wr)
-g = [v for k, v in res.items() if k.startswith("gemm")]
+g = [v for k, v in res.items() if k.startswith("gemm_f32") or k.startswith("conv8_c32")]      # the fp32 MFMA core
 n = sum(v["launches"] for v in g)
 res["_gemm_all"] = dict(launches=n, hbm_bytes_per_launch=sum(v["hbm_bytes_per_launch"] * v["launches"] for v in g) / max(n, 1))
 json.dump(res, open(sys.argv[3], "w"), indent=1)
