@@ -242,7 +242,14 @@ def main():
     run_steps(drv, args.warmup, args.steps)
     barrier()
     dt = parallel.max_over_ranks(time.perf_counter() - t0, device)
-    drv.check_length_index()
+    # On this synthetic recipe (burst counts up to L) the generator's length head saturates after ~2000 iterations and
+    # the reference raises IndexError there (src/model.py:44; the CPU oracle does after 1.2 epochs, DESIGN.md section
+    # 6).  The kernels clamp the index, so a long timing run stays valid; the condition is reported, not raised.
+    try:
+        drv.check_length_index()
+        saturated = False
+    except IndexError:
+        saturated = True
     ms_per_step = dt * 1e3 / args.steps
     steps_per_s = args.steps / dt
     # Whole-job aggregate.  The unit is one pass of the loop body over one batch of --batch rows.  Weak scaling: every
@@ -305,7 +312,7 @@ def main():
                        "global_batch": eng.B * world, "optimizer_steps_per_s": steps_per_s,
                        "samples_per_s": steps_per_s * eng.B * world,
                        "parallelism": f"dp{world}", "graphs": not args.no_graph, "pipelined": pipelined,
-                       "grouped_generator_forwards": grouped},
+                       "grouped_generator_forwards": grouped, "length_index_saturated": saturated},
             "roofline": {"bound": "mfma", "achieved": roof["tflops"], "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
                          "frac": roof["tflops"] / PEAK_F32_MFMA_TFLOPS, "traffic": traffic,
                          "traffic_note": "bytes/launch, rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command "
