@@ -15,7 +15,7 @@ dev = torch.device("cuda:0")
 for L in a.L:
     for B in a.B:
         args = argparse.Namespace(seq_len=L + 1, classes=100, latent_dim=500, batch=B, inst=max(200, 2 * B // 100 + 1),
-                                  penalty="div", overlap=0)
+                                  penalty="div", overlap=0, dp="weak")
         eng, _ = bench.build_engine(args, 0, 1, dev)
         eng.capture_graphs()
         bench.run_steps(eng, 0, 6)
@@ -24,7 +24,7 @@ for L in a.L:
         bench.run_steps(eng, 6, a.steps)
         torch.cuda.synchronize()
         dt = time.perf_counter() - t0
-        roof = bench.gemm_roofline(eng, n_iters=3)
+        roof = bench.gemm_roofline(eng, rep=4, rounds=2)
         print(json.dumps(dict(L=L, B=B, it_per_s=a.steps / dt, samples_per_s=a.steps * B / dt,
                               gemm_tflops=roof["tflops"], gemm_frac_of_f32_mfma_peak=roof["tflops"] / 157.3,
                               avg_us_per_gemm=roof["avg_us"])), flush=True)

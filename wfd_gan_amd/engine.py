@@ -278,7 +278,7 @@ class TrainEngine:
         b["DDF"] = z(B, self.ldl)
         # slab workspace: at least the largest raw product of a step (first DF conv block: B*L x 32, split-K x2)
         b["ws"] = torch.empty(max(workspace_mb * (1 << 18), B * S * 64), **f32)
-        b["ws2"] = torch.empty(64 * (1 << 18), **f32)        # slab workspace of the side lane
+        b["ws2"] = torch.empty(max(64 * (1 << 18), 2 * B * rup(S, 4)), **f32)        # slab workspace of the side lane
         b["ws_gf"] = torch.empty(max(16 * B * 2048, 1 << 20), **f32)   # slabs of a generator forward running ahead
         if stacked is not None:
             # GroupedTrainer: this engine is one slot of a stack; the buffers the batched generator forward writes are
