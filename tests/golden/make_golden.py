@@ -514,6 +514,36 @@ def make_df_train_case(ref_model, name, length, class_dim, batch, n_steps, seed)
 
 
 # ------------------------------------------------------------------------------------------------
+def make_cli_fixture():
+    """The command-line contracts of the three scripts on the path, read from the reference's own argparse calls
+    (ast of the source files; nothing is executed): flag names, dest-relevant options, types, defaults, required,
+    action.  tests/test_cpu_abi.py compares the build's parsers against it."""
+    import ast
+    out = {}
+    for script in ("mlp_df_wgan_train.py", "generate.py", "train_df.py"):
+        tree = ast.parse(open(os.path.join(REF_SRC, script)).read())
+        args = []
+        for node in ast.walk(tree):
+            if isinstance(node, ast.Call) and isinstance(node.func, ast.Attribute) and node.func.attr == "add_argument":
+                flags = [a.value for a in node.args if isinstance(a, ast.Constant)]
+                kw = {}
+                for k in node.keywords:
+                    if k.arg in ("type", ):
+                        kw["type"] = k.value.id if isinstance(k.value, ast.Name) else None
+                    elif k.arg in ("default", "required", "action"):
+                        try:
+                            kw[k.arg] = ast.literal_eval(k.value)
+                        except Exception:
+                            kw[k.arg] = None
+                args.append(dict(flags=flags, **kw))
+        out[script] = args
+        print(f"   {script}: {len(args)} arguments")
+    with open(os.path.join(HERE, "cli_contract.json"), "w") as f:
+        json.dump(out, f, indent=1, sort_keys=True)
+    print("   wrote cli_contract.json")
+
+
+# ------------------------------------------------------------------------------------------------
 def pin_script_end_to_end():
     """PIN C: unmodified reference trainer (runpy) vs oracle.train_loop.run_training, same seeds."""
     print("[script] running the unmodified reference trainer end-to-end (tiny config-1-like dataset)")
@@ -635,6 +665,8 @@ def main():
     if not args.only or args.only == "df_train":
         make_df_train_case(ref_model, "tiny", length=64, class_dim=5, batch=16, n_steps=3, seed=51)
         make_df_train_case(ref_model, "cfg", length=1400, class_dim=100, batch=16, n_steps=2, seed=52)
+    if not args.only or args.only == "cli":
+        make_cli_fixture()
     if not args.only or args.only == "gp":
         pin_gradient_penalty(ref_model)
     if not args.skip_script and (not args.only or args.only == "script"):

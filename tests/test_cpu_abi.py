@@ -85,3 +85,41 @@ def test_shard_rows_partitions():
         assert all(spans[i][1] == spans[i + 1][0] for i in range(w - 1))
         sizes = [b - a for a, b in spans]
         assert max(sizes) - min(sizes) <= 1
+
+
+def test_cli_contract_matches_reference_argparse():
+    """tests/golden/cli_contract.json holds the argparse calls of the reference's three scripts on the path (read from
+    their source by make_golden.py): every flag must be accepted by the build's parser under every alias, with the
+    same type and the same default.  (generate.py's --train / --test are accepted but not required here: the bulk
+    sampler reads the scaler from the model directory.)"""
+    import json
+    from wfd_gan_amd import generate, mlp_df_wgan_train, train_df
+    contract = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "cli_contract.json")))
+    mods = {"mlp_df_wgan_train.py": (mlp_df_wgan_train, ["-d", "X.npz", "--f_model", "df.ckpt"]),
+            "generate.py": (generate, ["-m", "model_dir"]),
+            "train_df.py": (train_df, ["X.npz"])}
+    sample = {"int": ("3", 3), "float": ("0.5", 0.5), "str": ("abc", "abc"), None: ("abc", "abc")}
+    for script, args in contract.items():
+        mod, base = mods[script]
+        ns0 = vars(mod.parse_args(base))
+        for a in args:
+            flags = a["flags"]
+            positional = not flags[0].startswith("-")
+            dest = flags[0] if positional else [f for f in flags if f.startswith("--")][0][2:]
+            assert dest in ns0, (script, dest)
+            if not positional and not a.get("required") and dest not in ("dir", "f_model", "model"):
+                assert ns0[dest] == a.get("default"), (script, dest, ns0[dest], a.get("default"))
+            if positional:
+                continue
+            for flag in flags:
+                if a.get("action") == "store_true":
+                    got = vars(mod.parse_args(base + [flag]))[dest]
+                    assert got is True, (script, flag)
+                else:
+                    text, want = sample[a.get("type")]
+                    argv = [x for x in base]
+                    if flag in argv or any(f in argv for f in flags):     # replace the required placeholder
+                        i = next(i for i, x in enumerate(argv) if x in flags)
+                        del argv[i:i + 2]
+                    got = vars(mod.parse_args(argv + [flag, text]))[dest]
+                    assert got == want and type(got) is type(want), (script, flag, got)
