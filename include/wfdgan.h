@@ -216,6 +216,13 @@ int wfd_gather_batch(const float* X, int ldX, const int* y, const long long* idx
 
 int wfd_onehot_rows(const int* labels, int M, int C, float* out, int ld, int col0, void* stream);
 
+/* preprocessing.MinMaxScaler().fit on the float64 feature matrix (src/mlp_df_wgan_train.py:132-133): per-column
+ * data_min_ / data_max_ (exact, any order); part: 2 * max_chunks * S doubles of scratch */
+int wfd_colminmax_f64(const double* X, long N, int S, double* part, int max_chunks, double* mn, double* mx, void* stream);
+/* MinMaxScaler.transform (X *= scale_; X += min_ in float64, two roundings) + the .float() of :184 */
+int wfd_minmax_transform_f64(const double* X, long N, int S, const double* scale, const double* min_, float* out,
+                             void* stream);
+
 /* --clip: my_clip over every row, src/mlp_df_wgan_train.py:82-91,122 (float64, in place) */
 int wfd_clip_bursts(double* X, long N, int S, double max_len, double max_out, double max_in, void* stream);
 

@@ -245,3 +245,24 @@ def test_bad_arguments_are_rejected():
         L.gemm_f32(0, t.data_ptr(), 64, t.data_ptr(), 64, t.data_ptr(), 64, 0, 0, 64, 64, 1, st)       # empty M
     with pytest.raises(WfdError):
         L.gemm_bf16_nt(t.data_ptr(), 64, t.data_ptr(), 64, 64, 64, 60, t.data_ptr(), 64, 0, 0, 0, 0, 0, st)   # K % 8
+
+
+@pytest.mark.parametrize("shape", [(1000, 41), (70001, 33), (5, 1401)])
+def test_minmax_fit_transform_on_device_is_bit_identical(shape):
+    """MinMaxScaler().fit_transform + .float() (src/mlp_df_wgan_train.py:132-133,184) on the device vs sklearn."""
+    from sklearn import preprocessing
+    from wfd_gan_amd import utils
+    rng = np.random.default_rng(0)
+    N, S = shape
+    X = rng.integers(-5, 2000, size=(N, S)).astype(np.float64) + rng.random((N, S)) * (rng.random(S) < 0.3)
+    X[:, 3] = 7.0                                   # constant column: scale_ = 1
+    X[:, 4] = 0.0
+    sk = preprocessing.MinMaxScaler()
+    want = torch.from_numpy(sk.fit_transform(X)).float()
+    got, scaler = utils.fit_transform_device(X, torch.device(DEV))
+    assert torch.equal(got.cpu(), want)
+    for attr in ("data_min_", "data_max_", "data_range_", "scale_", "min_"):
+        assert np.array_equal(getattr(scaler, attr), getattr(sk, attr)), attr
+    assert scaler.n_samples_seen_ == N and scaler.n_features_in_ == S
+    y = rng.random((3, S)).astype(np.float32)
+    assert np.array_equal(scaler.inverse_transform(y.copy()), sk.inverse_transform(y.copy()))

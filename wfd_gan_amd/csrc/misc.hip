@@ -281,6 +281,53 @@ __global__ void sample_post_mode_kernel(const float* __restrict__ Y, int ldy, in
     if (threadIdx.x == 0) len_out[m] = n;
 }
 
+
+// MinMaxScaler.fit on the float64 feature matrix (src/mlp_df_wgan_train.py:132-133): per-column min / max.
+// Stage 1: a block of 64 columns x 16 row groups reduces a chunk of rows; stage 2 folds the chunks.  min / max are
+// exact in any order, so the result is the bit pattern sklearn computes.
+__global__ void colminmax_partial_kernel(const double* __restrict__ X, long N, int S, long rows_per_chunk,
+                                         double* __restrict__ part) {
+    __shared__ double smn[16][64], smx[16][64];
+    const int c = blockIdx.x * 64 + threadIdx.x, g = threadIdx.y;
+    const long r0 = (long)blockIdx.y * rows_per_chunk, r1 = min(N, r0 + rows_per_chunk);
+    double mn = INFINITY, mx = -INFINITY;
+    if (c < S)
+        for (long r = r0 + g; r < r1; r += 16) {
+            const double v = X[r * S + c];
+            mn = fmin(mn, v);
+            mx = fmax(mx, v);
+        }
+    smn[g][threadIdx.x] = mn; smx[g][threadIdx.x] = mx;
+    __syncthreads();
+    if (g == 0 && c < S) {
+        for (int k = 1; k < 16; ++k) { mn = fmin(mn, smn[k][threadIdx.x]); mx = fmax(mx, smx[k][threadIdx.x]); }
+        part[((long)blockIdx.y * 2 + 0) * S + c] = mn;
+        part[((long)blockIdx.y * 2 + 1) * S + c] = mx;
+    }
+}
+__global__ void colminmax_final_kernel(const double* __restrict__ part, int nchunk, int S, double* __restrict__ mn_out,
+                                       double* __restrict__ mx_out) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= S) return;
+    double mn = INFINITY, mx = -INFINITY;
+    for (int k = 0; k < nchunk; ++k) {
+        mn = fmin(mn, part[((long)k * 2 + 0) * S + c]);
+        mx = fmax(mx, part[((long)k * 2 + 1) * S + c]);
+    }
+    mn_out[c] = mn; mx_out[c] = mx;
+}
+// MinMaxScaler.transform (X *= scale_; X += min_: two float64 roundings, no fused multiply-add) followed by the
+// .float() of :184 -> the fp32 matrix the training step reads
+__global__ void minmax_transform_kernel(const double* __restrict__ X, long total, int S, const double* __restrict__ scale,
+                                        const double* __restrict__ min_, float* __restrict__ out) {
+    for (long o = (long)blockIdx.x * blockDim.x + threadIdx.x; o < total; o += (long)gridDim.x * blockDim.x) {
+#pragma clang fp contract(off)          // two roundings, as numpy's X *= scale_; X += min_  (no fused multiply-add)
+        const int c = (int)(o % S);
+        const double t = X[o] * scale[c];
+        out[o] = (float)(t + min_[c]);
+    }
+}
+
 }  // namespace
 
 extern "C" {
@@ -407,5 +454,31 @@ int wfd_sample_post(const float* Y, int ldy, int M, int S, const double* min_, c
 }
 
 int wfd_version(void) { return 1; }
+
+int wfd_colminmax_f64(const double* X, long N, int S, double* part, int max_chunks, double* mn, double* mx, void* stream) {
+    if (!X || !part || !mn || !mx || N <= 0 || S <= 0 || max_chunks <= 0) return WFD_ERR_ARG;
+    long nchunk = (N + 255) / 256;
+    if (nchunk > max_chunks) nchunk = max_chunks;
+    const long rpc = (N + nchunk - 1) / nchunk;
+    nchunk = (N + rpc - 1) / rpc;
+    hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL(colminmax_partial_kernel, dim3((S + 63) / 64, (unsigned)nchunk), dim3(64, 16), 0, st, X, N, S, rpc, part);
+    WFD_CHECK_LAUNCH();
+    hipLaunchKernelGGL(colminmax_final_kernel, dim3((S + 255) / 256), dim3(256), 0, st, part, (int)nchunk, S, mn, mx);
+    WFD_CHECK_LAUNCH();
+    return WFD_OK;
+}
+
+int wfd_minmax_transform_f64(const double* X, long N, int S, const double* scale, const double* min_, float* out,
+                             void* stream) {
+    if (!X || !scale || !min_ || !out || N <= 0 || S <= 0) return WFD_ERR_ARG;
+    const long total = N * S;
+    long blocks = (total + 255) / 256;
+    if (blocks > 16384) blocks = 16384;
+    hipLaunchKernelGGL(minmax_transform_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, X, total, S, scale,
+                       min_, out);
+    WFD_CHECK_LAUNCH();
+    return WFD_OK;
+}
 
 }  // extern "C"

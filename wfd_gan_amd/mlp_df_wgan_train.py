@@ -24,7 +24,6 @@ from time import strftime
 import joblib
 import numpy as np
 import torch
-from sklearn import preprocessing
 
 from . import common as cm
 from . import parallel, utils
@@ -135,12 +134,12 @@ def main(argv=None):
         logger.info("Save back  the clipped dataset to {}".format(args.dir.split(".npz")[0] + "_clip.npz"))
     y = y - y.min()
 
-    scaler = preprocessing.MinMaxScaler()
-    Xs = scaler.fit_transform(X)                      # float64 on the host, once
+    # MinMaxScaler fit + transform + the loop's .float() on the device, once (bit-identical to the host path)
+    Xs_dev, scaler = utils.fit_transform_device(X, device)
     class_dim = len(np.unique(y))
-    N, seq_len = Xs.shape
+    N, seq_len = Xs_dev.shape
     assert seq_len > 1 and class_dim > 1
-    logger.info("X shape {}, y shape {}, class num: {}".format(Xs.shape, y.shape, class_dim))
+    logger.info("X shape {}, y shape {}, class num: {}".format(tuple(Xs_dev.shape), y.shape, class_dim))
 
     # modules in the reference's construction order (:150-153) so that a seed gives the same initial weights
     generator = Generator(seq_len, class_dim, args.latent_dim, scaler_min=scaler.data_min_[0],
@@ -168,7 +167,8 @@ def main(argv=None):
                       device=device, seed=rng_seed, **dp)
     if world > 1:       # identical replicas whatever the host seeding was
         parallel.broadcast_state_([eng.Gp.flat, eng.Dp.flat] + list(eng.Gbuf.values()))
-    eng.attach_dataset(torch.from_numpy(Xs), torch.from_numpy(y), shuffle_seed=seed)
+    eng.attach_dataset(Xs_dev, torch.from_numpy(y), shuffle_seed=seed)
+    del Xs_dev
     eng.auto_reshuffle = False        # the epoch loop below owns the permutation (ragged last batch)
     if not args.no_graph:
         eng.capture_graphs()
@@ -252,7 +252,7 @@ def main(argv=None):
                 fake_all = comm.all_gather(fake_all).reshape(-1, seq_len)
             if rank == 0:
                 sel = idx_all.cpu().numpy()
-                total_real = scaler.inverse_transform(Xs[sel])                           # float64
+                total_real = scaler.inverse_transform(scaler.transform(X[sel]))          # float64, as :288
                 total_fake = scaler.inverse_transform(fake_all.cpu().numpy())            # float32
                 np.savez_compressed(join(checkpointdir, "epoch_{}".format(epoch + 1)), x=total_real,
                                     recon_x=total_fake, label=y[sel])

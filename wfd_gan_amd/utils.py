@@ -41,3 +41,35 @@ def load_dataset(dir):
     """npz with 'features' (N, S) and 'labels' (N,) as extract.py writes it (src/utils.py:97-103)."""
     data = np.load(dir)
     return data["features"], data["labels"]
+
+
+def fit_transform_device(X: np.ndarray, device):
+    """``preprocessing.MinMaxScaler().fit_transform(X)`` followed by the ``.float()`` of the training loop
+    (src/mlp_df_wgan_train.py:132-133,184) on the device: returns (fp32 scaled features resident in HBM, a fitted
+    sklearn MinMaxScaler with the attributes the reference's scaler would have -- it is what ``model/scaler.gz``
+    stores).  Column min / max are exact reductions and the transform is the scaler's two float64 roundings, so the
+    result is bit-identical to the host path."""
+    import torch
+    from sklearn import preprocessing
+
+    from ._lib import lib
+    from .sampler import minmax_params
+    L = lib()
+    Xd = torch.from_numpy(np.ascontiguousarray(X, dtype=np.float64)).to(device)
+    N, S = Xd.shape
+    st = torch.cuda.current_stream(device).cuda_stream
+    max_chunks = 1024
+    part = torch.empty(2 * max_chunks * S, dtype=torch.float64, device=device)
+    mn, mx = torch.empty(S, dtype=torch.float64, device=device), torch.empty(S, dtype=torch.float64, device=device)
+    L.colminmax_f64(Xd.data_ptr(), N, S, part.data_ptr(), max_chunks, mn.data_ptr(), mx.data_ptr(), st)
+    dmin, dmax = mn.cpu().numpy(), mx.cpu().numpy()
+    scaler = preprocessing.MinMaxScaler()
+    scaler.fit(np.stack([dmin, dmax]))          # two rows carrying the extrema: identical data_min_/max_/scale_/min_
+    scaler.n_samples_seen_ = N
+    scale, min_ = minmax_params(dmin, dmax)
+    assert np.array_equal(scale, scaler.scale_) and np.array_equal(min_, scaler.min_)
+    out = torch.empty(N, S, dtype=torch.float32, device=device)
+    sd, md = torch.from_numpy(scale).to(device), torch.from_numpy(min_).to(device)
+    L.minmax_transform_f64(Xd.data_ptr(), N, S, sd.data_ptr(), md.data_ptr(), out.data_ptr(), st)
+    torch.cuda.synchronize(device)
+    return out, scaler
