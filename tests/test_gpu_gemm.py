@@ -164,3 +164,24 @@ def test_conv8_lds_resident_kernel(cfg, pad):
                            0, 0, Dd.data_ptr(), Cout, 3, st)
     want = ref * torch.where(D > 0, torch.ones(()), D + 1).double() * scale.double()
     assert (out.cpu().double() - want).abs().max().item() / scale_ref < 2e-5
+
+
+@pytest.mark.parametrize("shape", [(2048, 1536, 512), (1100, 1401, 2048), (8192, 512, 600), (1031, 3000, 68)])
+def test_gemm_nt_tall_tile(shape):
+    """Large-M NT products with one split take the 128x128 tile kernel: ragged M / N / K edges, raw and fused."""
+    from wfd_gan_amd._lib import lib
+    M, N, K = shape
+    assert _run_gemm(0, M, N, K, splits=1) < 2e-5
+    L = lib()
+    g = torch.Generator().manual_seed(5)
+    A, B = torch.randn(M, K, generator=g), torch.randn(N, K, generator=g)
+    scale, shift = torch.rand(N, generator=g) + 0.5, torch.randn(N, generator=g)
+    Ad, Bd, sd, hd = (t.to("cuda:0") for t in (A, B, scale, shift))
+    ldo = (N + 3) // 4 * 4
+    out = torch.full((M, ldo), float("nan"), device="cuda:0")
+    L.gemm_f32_fused(0, Ad.data_ptr(), K, Bd.data_ptr(), K, out.data_ptr(), ldo, M, N, K, 1, sd.data_ptr(), hd.data_ptr(), 1,
+                     0, 0, 0, torch.cuda.current_stream().cuda_stream)
+    want = torch.relu((A.double() @ B.double().T) * scale.double() + shift.double())
+    got = out[:, :N].cpu().double()
+    assert torch.isfinite(got).all()
+    assert (got - want).abs().max().item() / want.abs().max().item() < 2e-5

@@ -358,6 +358,120 @@ int launch_conv8_c32(const GemmArgs& g, hipStream_t st) {
 // the LDS-resident form pays when there are enough 128-row tiles to fill the chip
 inline bool use_conv8_c32(int M, int Cin, int Cout) { return Cin == C32 && (long)cdiv(M, C32_ROWS) * cdiv(Cout, 32) >= 128; }
 
+// ---------------------------------------------------------------------------------------------------------------
+// Large-M NT product (bulk sampling, large-batch training): 128x128x32 tile, 2x2 waves of 64x64 -- four 32x32
+// accumulators per wave, so every A / B fragment read from LDS feeds two MFMAs instead of one (half the LDS traffic per
+// FLOP of the 64x64 tile above).  Same staging (global -> registers -> LDS, double buffered, [row][36] tiles), no K
+// split (used only when the 128x128 tiles alone fill the chip), workgroup ids remapped so that one XCD walks
+// neighbouring tiles.  Dynamic LDS: 2 x (128 + 128) x 36 floats = 73.7 KB -> two workgroups per CU.
+constexpr int T128 = 128, T128_F = T128 * LDK;            // floats per operand tile
+
+template <bool EPI>
+__global__ __launch_bounds__(NTHREADS) void gemm_f32_nt128_kernel(GemmArgs g, int gx, int gy) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1, i = lane & 31, h = lane >> 5;
+    int bid = blockIdx.x;
+    const int nb = gx * gy;
+    if ((nb & 7) == 0) bid = (bid & 7) * (nb >> 3) + (bid >> 3);
+    const int m0 = (bid / gx) * T128, n0 = (bid % gx) * T128;
+    const int nk = (g.K + BK - 1) / BK;
+
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+
+    float ra[2][8], rb[2][8];
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+        load_tile<true, 4, false>(ra[q], g.A, g.lda, m0 + 64 * q, g.M, 0, g.K, tid, 0, 0, 0);
+        load_tile<true, 4, false>(rb[q], g.B, g.ldb, n0 + 64 * q, g.N, 0, g.K, tid, 0, 0, 0);
+    }
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+        store_tile<true, 4>(ra[q], smem + 64 * q * LDK, tid);
+        store_tile<true, 4>(rb[q], smem + T128_F + 64 * q * LDK, tid);
+    }
+    __syncthreads();
+    int cur = 0;
+    for (int kt = 0; kt < nk; ++kt) {
+        const bool more = kt + 1 < nk;
+        if (more) {
+            const int k0 = (kt + 1) * BK;
+#pragma unroll
+            for (int q = 0; q < 2; ++q) {
+                load_tile<true, 4, false>(ra[q], g.A, g.lda, m0 + 64 * q, g.M, k0, g.K, tid, 0, 0, 0);
+                load_tile<true, 4, false>(rb[q], g.B, g.ldb, n0 + 64 * q, g.N, k0, g.K, tid, 0, 0, 0);
+            }
+        }
+        const float* a_s = smem + cur * 2 * T128_F;
+        const float* b_s = a_s + T128_F;
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) {
+            f32x4 af[2], bf[2];
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+                af[t] = read_frag<true>(a_s, wm * 64 + 32 * t, kk, i, h);
+                bf[t] = read_frag<true>(b_s, wn * 64 + 32 * t, kk, i, h);
+            }
+#pragma unroll
+            for (int s2 = 0; s2 < 4; ++s2)
+#pragma unroll
+                for (int a = 0; a < 2; ++a)
+#pragma unroll
+                    for (int b = 0; b < 2; ++b)
+                        acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[a][s2], bf[b][s2], acc[a][b], 0, 0, 0);
+        }
+        if (more) {
+            float* nxt = smem + (cur ^ 1) * 2 * T128_F;
+#pragma unroll
+            for (int q = 0; q < 2; ++q) {
+                store_tile<true, 4>(ra[q], nxt + 64 * q * LDK, tid);
+                store_tile<true, 4>(rb[q], nxt + T128_F + 64 * q * LDK, tid);
+            }
+        }
+        __syncthreads();
+        cur ^= 1;
+    }
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b) {
+            const int col = n0 + wn * 64 + 32 * b + i;
+            if (col >= g.N) continue;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = m0 + wm * 64 + 32 * a + (r & 3) + 8 * (r >> 2) + 4 * h;
+                if (row >= g.M) continue;
+                if constexpr (EPI) g.P[(long)row * g.ldp + col] = epi_apply(g, acc[a][b][r], row, col);
+                else g.P[(long)row * g.ldp + col] = acc[a][b][r];
+            }
+        }
+}
+
+template <bool EPI>
+int launch_nt128(const GemmArgs& g, hipStream_t st) {
+    static bool attr = false;
+    const size_t lds = (size_t)4 * T128_F * sizeof(float);
+    if (!attr) {
+        (void)hipFuncSetAttribute((const void*)gemm_f32_nt128_kernel<EPI>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        attr = true;
+    }
+    const int gx = cdiv(g.N, T128), gy = cdiv(g.M, T128);
+    hipLaunchKernelGGL((gemm_f32_nt128_kernel<EPI>), dim3(gx * gy), dim3(NTHREADS), lds, st, g, gx, gy);
+    WFD_CHECK_LAUNCH();
+    return WFD_OK;
+}
+
+// the tall-tile form pays when its tiles alone give every CU work (no K split needed)
+inline bool use_nt128(int M, int N, int K, bool va4, bool vb4) {
+    return va4 && vb4 && M >= 1024 && K >= 64 && (long)cdiv(M, T128) * cdiv(N, T128) >= 192;
+}
+
 template <bool AKC, bool BKC, bool IM2COL>
 int launch_gemm(const GemmArgs& g, int splits, bool va4, bool vb4, hipStream_t st) {
     if (g.narrow) {
@@ -403,7 +517,10 @@ int wfd_gemm_f32(int layout, const float* A, int lda, const float* B, int ldb, f
     hipStream_t st = (hipStream_t)stream;
     const bool va4 = aligned16(A) && (lda % 4 == 0), vb4 = aligned16(B) && (ldb % 4 == 0);
     switch (layout) {
-        case 0: if (lda < K || ldb < K) return WFD_ERR_ARG; return launch_gemm<true, true, false>(g, splits, va4, vb4, st);
+        case 0:
+            if (lda < K || ldb < K) return WFD_ERR_ARG;
+            if (splits == 1 && use_nt128(M, N, K, va4, vb4)) return launch_nt128<false>(g, st);
+            return launch_gemm<true, true, false>(g, splits, va4, vb4, st);
         case 1: if (lda < K || ldb < N) return WFD_ERR_ARG; return launch_gemm<true, false, false>(g, splits, va4, vb4, st);
         case 2: if (lda < M || ldb < N) return WFD_ERR_ARG; return launch_gemm<false, false, false>(g, splits, va4, vb4, st);
         default: return WFD_ERR_ARG;
@@ -445,7 +562,10 @@ int wfd_gemm_f32_fused(int layout, const float* A, int lda, const float* B, int 
     hipStream_t st = (hipStream_t)stream;
     const bool va4 = aligned16(A) && (lda % 4 == 0), vb4 = aligned16(B) && (ldb % 4 == 0);
     switch (layout) {
-        case 0: if (lda < K || ldb < K) return WFD_ERR_ARG; return launch_gemm<true, true, false>(g, 1, va4, vb4, st);
+        case 0:
+            if (lda < K || ldb < K) return WFD_ERR_ARG;
+            if (use_nt128(M, N, K, va4, vb4)) return launch_nt128<true>(g, st);
+            return launch_gemm<true, true, false>(g, 1, va4, vb4, st);
         case 1: if (lda < K || ldb < N) return WFD_ERR_ARG; return launch_gemm<true, false, false>(g, 1, va4, vb4, st);
         case 2: if (lda < M || ldb < N) return WFD_ERR_ARG; return launch_gemm<false, false, false>(g, 1, va4, vb4, st);
         default: return WFD_ERR_ARG;
