@@ -66,7 +66,8 @@ def build_engine(args, rank, world, device):
     pg = None
     eng = TrainEngine(S, C, Z, B, float(dmin[0]), float(dmax[0]), G.state_dict(), D.state_dict(), F.state_dict(),
                       lr=2e-4, alpha=0.02, n_critic=3, penalty=args.penalty, device=device, seed=1234 + rank,
-                      process_group=pg, world_size=world, overlap=bool(args.overlap), rank=rank, sync_bn=strong)
+                      process_group=pg, world_size=world, overlap=bool(args.overlap), rank=rank, sync_bn=strong,
+                      operands=args.operands)
     eng.attach_dataset(Xs, y, shuffle_seed=0 if strong else rank)
     return eng, (dmin.double().cpu().numpy(), dmax.double().cpu().numpy())
 
@@ -119,6 +120,7 @@ def gemm_roofline(eng, plans=None, rep=16, rounds=3):
             else:
                 M, N, K = a[1] * a[2], a[6], 8 * a[3]
             calls.append((fn, a, 2.0 * M * N * K, weight))
+    L.set_gemm_mode(eng.gemm_mode)                     # the plans' operand mode (Plan.run sets it the same way)
     side = torch.cuda.Stream()
     side.wait_stream(torch.cuda.current_stream())
     with torch.cuda.stream(side):                      # load every kernel variant before capturing
@@ -146,6 +148,7 @@ def gemm_roofline(eng, plans=None, rep=16, rounds=3):
         flops += fl * weight
         ms += tot / rounds * weight
         n += weight
+    L.set_gemm_mode(0)
     return dict(launches=n, avg_flops=flops / n, avg_us=ms * 1e3 / n, tflops=flops / (ms * 1e-3) / 1e12)
 
 
@@ -191,6 +194,9 @@ def main():
     ap.add_argument("--inst", type=int, default=1000)
     ap.add_argument("--latent_dim", type=int, default=500)
     ap.add_argument("--penalty", default="div", choices=["div", "gp"])
+    ap.add_argument("--operands", default="f32", choices=["f32", "bf16", "bf16x3"],
+                    help="contraction operands: f32 = f32-input MFMA (parity path, the default); bf16 = bf16 operands / "
+                         "fp32 accumulate; bf16x3 = split-bf16 (hi*hi + hi*lo + lo*hi) on the bf16 matrix pipe")
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--overlap", type=int, default=0, help="1: independent branches of a step on a side stream")
     ap.add_argument("--dp", default="weak", choices=["weak", "strong"],
@@ -298,6 +304,13 @@ def main():
         sdt16 = parallel.max_over_ranks(time.perf_counter() - t1, device)
         samp["bf16_operands_traces_per_s"] = world * nchunks * chunk / sdt16
 
+    # roofline of the contraction core in the mode that ran: f32-input MFMA 157.3 TF; bf16 MFMA 2.5 PF dense, of which
+    # the split-bf16 mode spends three instructions per product term (peak / 3 in fp32-equivalent FLOP)
+    peak = {"f32": PEAK_F32_MFMA_TFLOPS, "bf16": 2500.0, "bf16x3": 2500.0 / 3}[args.operands]
+    dtype = {"f32": "f32", "bf16": "bf16 operands, f32 accumulate (data f32 in HBM)",
+             "bf16x3": "f32 via split-bf16 (3 bf16 MFMAs per product), f32 accumulate"}[args.operands]
+    core = ("fp32 MFMA core: gemm_f32_kernel (all layouts, implicit-GEMM conv) + conv8_c32_kernel" if args.operands == "f32"
+            else "bf16 MFMA core over fp32 data: gemm_mx_kernel (all layouts, implicit-GEMM conv)")
     if rank == 0:
         out = {
             "metric": "WGAN train iterations/s (100-class, L=1400, fp32; one iteration = loop body on one 64-row batch: "
@@ -305,19 +318,20 @@ def main():
             "value": its * 1.0, "unit": "iterations/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "strong" if (args.dp == "strong" and world > 1) else "weak",
             "vs_baseline": None,
-            "dtype": "f32", "data": "synthetic",
+            "dtype": dtype, "data": "synthetic",
             "config": {"workload": "configs[1]: 100 sites x 1000 inst synthetic bursts, L=1400 (S=1401), batch "
                                    f"{args.batch}/GPU, latent {args.latent_dim}, n_critic 3, alpha 0.02, RMSprop 2e-4, "
                                    f"penalty={args.penalty} ({'W-div k=2 p=6, what the reference runs' if args.penalty == 'div' else 'WGAN-GP interpolate'})",
                        "global_batch": eng.B * world, "optimizer_steps_per_s": steps_per_s,
                        "samples_per_s": steps_per_s * eng.B * world,
                        "parallelism": f"dp{world}", "graphs": not args.no_graph, "pipelined": pipelined,
-                       "grouped_generator_forwards": grouped, "length_index_saturated": saturated},
-            "roofline": {"bound": "mfma", "achieved": roof["tflops"], "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
-                         "frac": roof["tflops"] / PEAK_F32_MFMA_TFLOPS, "traffic": traffic,
+                       "grouped_generator_forwards": grouped, "length_index_saturated": saturated,
+                       "operands": args.operands},
+            "roofline": {"bound": "mfma", "achieved": roof["tflops"], "peak": peak, "unit": "TFLOP/s",
+                         "frac": roof["tflops"] / peak, "traffic": traffic if args.operands == "f32" else None,
                          "traffic_note": "bytes/launch, rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command "
                                          "(profiles/pmc_traffic.json; FETCH x2 per MI355X_MICROARCH HBM section)",
-                         "kernel": "fp32 MFMA core: gemm_f32_kernel (all layouts, implicit-GEMM conv) + conv8_c32_kernel", "launches_timed": roof["launches"],
+                         "kernel": core, "launches_timed": roof["launches"],
                          "avg_flops_per_launch": roof["avg_flops"], "avg_us_per_launch": roof["avg_us"]},
         }
         if samp:

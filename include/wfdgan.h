@@ -25,6 +25,15 @@ int wfd_version(void);
 
 /* ---- dense contractions (fp32 MFMA, exact f32 products) ------------------------------------------------ */
 
+/* Operand mode of every contraction entry point below (process-wide; read when a launch is issued or captured):
+ *   0  f32-input MFMA, exact f32 products -- the parity path and the default;
+ *   1  "bf16":   fp32 data converted to bf16 on its way into LDS, bf16 MFMA, fp32 accumulate (BASELINE config 4);
+ *   2  "bf16x3": x = hi + lo split into two bf16, product = hi*hi + hi*lo + lo*hi on the bf16 pipe (products carry
+ *                ~1e-5 relative error instead of 6e-8, at 16/3 of the f32 MFMA rate).
+ * Buffers in HBM stay fp32 in every mode.  No counterpart in the reference (torch's default fp32 matmul = mode 0). */
+int wfd_set_gemm_mode(int mode);
+int wfd_get_gemm_mode(void);
+
 /* Split count the library recommends for an MxNxK product (fills 256 CUs when the batch dimension is tiny). */
 int wfd_gemm_pick_splits(int M, int N, int K);
 

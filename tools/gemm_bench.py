@@ -21,6 +21,9 @@ shapes = [  # (name, layout, M, N, K, lda, ldb)
     ("sample L3 NT", 0, 8192, 2048, 1024, 1024, 1024), ("sample L4 NT", 0, 8192, 1401, 2048, 2048, 2048),
 ]
 ws = torch.empty(1 << 28, device=dev)
+mode = int(sys.argv[1]) if len(sys.argv) > 1 else 0
+L.set_gemm_mode(mode)
+print("gemm mode", mode, flush=True)
 for name, lay, M, N, K, lda, ldb in shapes:
     ra = M if lay != 2 else K
     rb = N if lay == 0 else K

@@ -16,7 +16,7 @@
 // [row][36] and read with one ds_read_b128 per 4 MFMAs (conflict-free: 36 mod 64 walks all 16 slots); an
 // m-contiguous one is stored [k][68] and read with ds_read_b32.  Lane half h of MFMA step s consumes
 // k = 8*kk + 4*h + s for BOTH operands, so the k-permutation inside a tile is consistent.
-#include "common.h"
+#include "gemm_args.h"
 
 namespace {
 
@@ -24,42 +24,6 @@ constexpr int BM = 64, BN = 64, BK = 32, NTHREADS = 256;
 constexpr int LDK = BK + 4;  // row stride of a k-contiguous tile  [64][36]
 constexpr int LDM = BM + 4;  // row stride of an m-contiguous tile [32][68]
 constexpr int TILE_F = 64 * LDK;  // 2304 floats >= 32*68 = 2176
-
-struct GemmArgs {
-    const float* A;
-    const float* B;
-    float* P;
-    int M, N, K;
-    int lda, ldb, ldp;
-    long slab_stride;   // floats between split slabs
-    int ktiles_per_split;
-    int convL, convCin, convPad;  // IM2COL only
-    int narrow;                   // N <= 32: the two wave columns split each k-tile instead of the N range
-    // fused epilogue (splits == 1 only): 0 raw; 1 out = act(acc*scale[n]+shift[n]); 2 out = acc*f(D[m][n])*scale[n]
-    int epi, act, dmode, ldd;
-    const float* scale;
-    const float* shift;
-    const float* D;
-};
-
-__device__ __forceinline__ float epi_apply(const GemmArgs& g, float v, int row, int col) {
-    if (g.epi == 1) {
-        const float sh = g.shift ? g.shift[col] : 0.f;
-        v = g.scale ? __fmaf_rn(v, g.scale[col], sh) : v + sh;
-        if (g.act == 1) v = fmaxf(v, 0.f);
-        else if (g.act == 2) v = v > 0.f ? v : expm1f(v);
-        else if (g.act == 3) v = 1.0f / (1.0f + expf(-v));
-    } else if (g.epi == 2) {
-        if (g.dmode) {
-            const float d = g.D[(long)row * g.ldd + col];
-            if (g.dmode == 1) v *= d;
-            else if (g.dmode == 2) v = d > 0.f ? v : 0.f;
-            else v = d > 0.f ? v : v * (d + 1.f);
-        }
-        if (g.scale) v *= g.scale[col];
-    }
-    return v;
-}
 
 // ---- global -> register staging -------------------------------------------------------------------------
 // KC = operand is k-contiguous in global memory ([rows][K], ld); else row(k)-major with the m/n index contiguous.
@@ -484,9 +448,23 @@ int launch_gemm(const GemmArgs& g, int splits, bool va4, bool vb4, hipStream_t s
 
 inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
 
+// operand mode of the contraction entry points: 0 = f32-input MFMA (exact f32 products, the parity path),
+// 1 = bf16 operands, 2 = split-bf16 x3 (gemm_mx.hip).  Process-wide; read when a launch is issued (or captured).
+int g_gemm_mode = 0;
+
 }  // namespace
 
+int wfd_mx_launch(const GemmArgs& g, int layout, int splits, int terms, hipStream_t st);     // gemm_mx.hip
+
 extern "C" {
+
+int wfd_set_gemm_mode(int mode) {
+    if (mode < 0 || mode > 2) return WFD_ERR_ARG;
+    g_gemm_mode = mode;
+    return WFD_OK;
+}
+
+int wfd_get_gemm_mode(void) { return g_gemm_mode; }
 
 // Number of K splits the library would pick for an (M,N,K) product: enough workgroups to cover the 256 CUs about
 // twice, never thinner than 2 k-tiles per split.  The caller sizes the slab workspace with it.
@@ -516,6 +494,10 @@ int wfd_gemm_f32(int layout, const float* A, int lda, const float* B, int ldb, f
     g.narrow = N <= 32;
     hipStream_t st = (hipStream_t)stream;
     const bool va4 = aligned16(A) && (lda % 4 == 0), vb4 = aligned16(B) && (ldb % 4 == 0);
+    if (g_gemm_mode && va4 && vb4 && layout >= 0 && layout <= 2) {
+        if (layout == 2 ? (lda < M || ldb < N) : (lda < K || ldb < (layout == 0 ? K : N))) return WFD_ERR_ARG;
+        return wfd_mx_launch(g, layout, splits, g_gemm_mode, st);
+    }
     switch (layout) {
         case 0:
             if (lda < K || ldb < K) return WFD_ERR_ARG;
@@ -542,6 +524,7 @@ int wfd_conv8_gemm_f32(const float* X, int Bn, int L, int Cin, int pad, const fl
     g.convL = L; g.convCin = Cin; g.convPad = pad;
     g.narrow = Cout <= 32;
     if (splits > 1 && slab_stride < (long)g.M * ldp) return WFD_ERR_ARG;
+    if (g_gemm_mode) return wfd_mx_launch(g, 3, splits, g_gemm_mode, (hipStream_t)stream);
     if (splits == 1 && use_conv8_c32(g.M, Cin, Cout)) return launch_conv8_c32<false>(g, (hipStream_t)stream);
     return launch_gemm<true, true, true>(g, splits, true, true, (hipStream_t)stream);
 }
@@ -561,6 +544,10 @@ int wfd_gemm_f32_fused(int layout, const float* A, int lda, const float* B, int 
     g.epi = epi; g.act = act; g.dmode = dmode; g.ldd = ldd; g.scale = scale; g.shift = shift; g.D = D;
     hipStream_t st = (hipStream_t)stream;
     const bool va4 = aligned16(A) && (lda % 4 == 0), vb4 = aligned16(B) && (ldb % 4 == 0);
+    if (g_gemm_mode && va4 && vb4 && layout >= 0 && layout <= 2) {
+        if (layout == 2 ? (lda < M || ldb < N) : (lda < K || ldb < (layout == 0 ? K : N))) return WFD_ERR_ARG;
+        return wfd_mx_launch(g, layout, 1, g_gemm_mode, st);
+    }
     switch (layout) {
         case 0:
             if (lda < K || ldb < K) return WFD_ERR_ARG;
@@ -583,6 +570,7 @@ int wfd_conv8_gemm_f32_fused(const float* X, int Bn, int L, int Cin, int pad, co
     g.convL = L; g.convCin = Cin; g.convPad = pad;
     g.narrow = Cout <= 32;
     g.epi = epi; g.act = act; g.dmode = dmode; g.ldd = ldd; g.scale = scale; g.shift = shift; g.D = D;
+    if (g_gemm_mode) return wfd_mx_launch(g, 3, 1, g_gemm_mode, (hipStream_t)stream);
     if (use_conv8_c32(g.M, Cin, Cout)) return launch_conv8_c32<true>(g, (hipStream_t)stream);
     return launch_gemm<true, true, true>(g, 1, true, true, (hipStream_t)stream);
 }

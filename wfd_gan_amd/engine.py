@@ -36,6 +36,8 @@ D_PARAM_SPECS = lambda S, C: [  # Discriminator, src/model.py:56-67
 ]
 G_BUFFER_KEYS = ["model.3.running_mean", "model.3.running_var", "model.6.running_mean", "model.6.running_var"]
 
+GEMM_MODES = {"f32": 0, "bf16": 1, "bf16x3": 2}
+
 DF_CONVS = [  # (conv prefix, bn prefix, Cin, Cout, act, pool_after) -- src/model.py:140-185
     ("layer1.0", "layer1.1", 1, 32, ACT_ELU, False), ("layer1.3", "layer1.4", 32, 32, ACT_ELU, True),
     ("layer2.0", "layer2.1", 32, 64, ACT_RELU, False), ("layer2.3", "layer2.4", 64, 64, ACT_RELU, True),
@@ -166,7 +168,7 @@ class TrainEngine:
                  seed: int = 0, workspace_mb: int = 256, process_group=None, world_size: int = 1,
                  share: Optional["TrainEngine"] = None, overlap: bool = False, force_sync: bool = False,
                  sync_bn: bool = False, rank: int = 0, stacked: Optional[Dict[str, torch.Tensor]] = None,
-                 slot: int = 0):
+                 slot: int = 0, operands: str = "f32"):
         """Data parallel, two modes:
           * sync_bn=False (weak scaling, DDP semantics): every rank trains on its own ``batch`` rows with local
             BatchNorm statistics and a local selected-row count; gradients are averaged over ranks.
@@ -178,6 +180,11 @@ class TrainEngine:
             raise RuntimeError("wfd_gan_amd.TrainEngine needs a HIP device: there is no CPU path")
         if penalty not in ("div", "gp"):
             raise ValueError("penalty must be 'div' (what the reference runs) or 'gp' (src/utils.py:64-84)")
+        if operands not in GEMM_MODES:
+            raise ValueError(f"operands must be one of {sorted(GEMM_MODES)}")
+        # contraction operands: "f32" = f32-input MFMA (exact products; the parity path), "bf16" = bf16 operands /
+        # fp32 accumulate (BASELINE config 4), "bf16x3" = split-bf16 (hi*hi + hi*lo + lo*hi).  HBM stays fp32.
+        self.operands, self.gemm_mode = operands, GEMM_MODES[operands]
         self.L = lib()
         self.dev = torch.device(device)
         S, C, Z, B = seq_len, class_dim, latent_dim, batch
@@ -412,7 +419,7 @@ class TrainEngine:
         part: "all" = the whole D-step; "gf" = only its head (batch gather, z / mask draws, generator forward), which
         depends on nothing the critic update writes; "rest" = everything after it (PipelinedTrainer)."""
         B, M, S, C, Z, b, D = self.B, self.M, self.S, self.C, self.Z, self.buf, self.Dp
-        p = Plan(b["ws"] if part != "gf" else b["ws_gf"], b["ws2"], self.overlap)
+        p = Plan(b["ws"] if part != "gf" else b["ws_gf"], b["ws2"], self.overlap, self.gemm_mode)
         st = self.iter_state.data_ptr() if part != "gf" else self.gf_state.data_ptr()
         if part in ("rest", "rest_draw"):
             if part == "rest_draw":
@@ -582,7 +589,7 @@ class TrainEngine:
 
     def _build_g_plan(self, fast: bool = False) -> Plan:
         B, S, C, Z, b, G = self.B, self.S, self.C, self.Z, self.buf, self.Gp
-        p = Plan(b["ws"], b["ws2"], self.overlap)
+        p = Plan(b["ws"], b["ws2"], self.overlap, self.gemm_mode)
         st = self.iter_state.data_ptr()
         if fast:
             t = b["gMKflat"]
@@ -909,7 +916,7 @@ class PipelinedTrainer:
         self.e = [eng, TrainEngine(eng.S, eng.C, eng.Z, eng.B, eng.scaler_min, eng.scaler_max, {}, {}, {}, lr=eng.lr,
                                    alpha=eng.alpha, n_critic=eng.n_critic, penalty=eng.penalty, lambda_gp=eng.lambda_gp,
                                    device=eng.dev, seed=eng.seed + 0x51ED, process_group=eng.pg, world_size=eng.world,
-                                   share=eng, rank=eng.rank)]
+                                   share=eng, rank=eng.rank, operands=eng.operands)]
         other = self.e[1]
         for name in ("data_X", "data_y", "N", "perm", "perm_gen", "iters_per_epoch"):
             setattr(other, name, getattr(eng, name))
@@ -1038,7 +1045,7 @@ class GroupedTrainer:
         self.e = [TrainEngine(eng.S, eng.C, eng.Z, eng.B, eng.scaler_min, eng.scaler_max, {}, {}, {}, lr=eng.lr,
                               alpha=eng.alpha, n_critic=n, penalty=eng.penalty, lambda_gp=eng.lambda_gp, device=dev,
                               seed=eng.seed + 0x9E37 * (k + 1), process_group=eng.pg, world_size=eng.world, share=eng,
-                              rank=eng.rank, stacked=self.stacked, slot=k) for k in range(n)]
+                              rank=eng.rank, stacked=self.stacked, slot=k, operands=eng.operands) for k in range(n)]
         self.base = eng
         for e in self.e:
             for name in ("data_X", "data_y", "N", "perm", "perm_gen", "iters_per_epoch"):
@@ -1048,7 +1055,7 @@ class GroupedTrainer:
         self.head = self._build_head()
         self.rest = [e._build_d_plan(fast=True, part="rest_draw") for e in self.e]
         self.gstep = self.e[n - 1]._build_g_plan(fast=True)
-        self.group = Plan(self.ws)
+        self.group = Plan(self.ws, gemm_mode=eng.gemm_mode)
         self.group.extend(self.head)
         for r in self.rest:
             self.group.extend(r)
@@ -1063,7 +1070,7 @@ class GroupedTrainer:
         eng, n, L = self.base, self.n, self.base.L
         B, S, C, Z, G, st = eng.B, eng.S, eng.C, eng.Z, eng.Gp.p, self.stacked
         M = n * B
-        p = Plan(self.ws)
+        p = Plan(self.ws, gemm_mode=eng.gemm_mode)
         state = eng.gf_state.data_ptr()
         xc = st["XC"]                                   # [n][2*Mslot][ldx]
         slot_stride = xc.stride(0)

@@ -45,8 +45,12 @@ class Plan:
 
     _side_streams = {}
 
-    def __init__(self, workspace: torch.Tensor, side_workspace: Optional[torch.Tensor] = None, overlap: bool = True):
+    def __init__(self, workspace: torch.Tensor, side_workspace: Optional[torch.Tensor] = None, overlap: bool = True,
+                 gemm_mode: int = 0):
         self.L = lib()
+        # operand mode of the plan's contractions (include/wfdgan.h, wfd_set_gemm_mode): 0 f32-input MFMA (parity path),
+        # 1 bf16 operands, 2 split-bf16 x3.  Set around run(), so plans of different modes can coexist in a process.
+        self.gemm_mode = int(gemm_mode)
         self.two = side_workspace is not None          # side lane available (own slab workspace)
         self.ws_lane = [workspace, side_workspace if self.two else workspace]
         self.calls: List[Tuple] = []
@@ -66,6 +70,8 @@ class Plan:
         self.calls.append((fn, args, self.lane))
 
     def extend(self, other: "Plan"):
+        if other.gemm_mode != self.gemm_mode:
+            raise ValueError("plans of different gemm modes cannot be concatenated")
         self.calls += other.calls
 
     def host(self, thunk):
@@ -97,6 +103,16 @@ class Plan:
         return Plan._Side(self)
 
     def run(self, serial: bool = False):
+        prev = self.L.get_gemm_mode()
+        if prev != self.gemm_mode:
+            self.L.set_gemm_mode(self.gemm_mode)
+        try:
+            self._run(serial)
+        finally:
+            if prev != self.gemm_mode:
+                self.L.set_gemm_mode(prev)
+
+    def _run(self, serial: bool = False):
         main = torch.cuda.current_stream()
         side = None
         if self.overlap and not serial:
@@ -120,7 +136,7 @@ class Plan:
 
     def stages(self):
         """[Plan | thunk, ...]: maximal runs of launches separated by host actions."""
-        mk = lambda: Plan(self.ws_lane[0], self.ws_lane[1] if self.two else None, self.overlap)
+        mk = lambda: Plan(self.ws_lane[0], self.ws_lane[1] if self.two else None, self.overlap, self.gemm_mode)
         out, cur = [], mk()
         for fn, a, lane in self.calls:
             if fn is HOST:
