@@ -130,6 +130,7 @@ def gemm_roofline(eng, plans=None, rep=16, rounds=3):
     torch.cuda.synchronize()
     flops = ms = 0.0
     n = 0
+    per_call = []
     for fn, a, fl, weight in calls:
         g = torch.cuda.CUDAGraph()
         with torch.cuda.graph(g):
@@ -148,8 +149,10 @@ def gemm_roofline(eng, plans=None, rep=16, rounds=3):
         flops += fl * weight
         ms += tot / rounds * weight
         n += weight
+        per_call.append((gemm_fns[fn], fl, tot / rounds * 1e3, weight, a))
     L.set_gemm_mode(0)
-    return dict(launches=n, avg_flops=flops / n, avg_us=ms * 1e3 / n, tflops=flops / (ms * 1e-3) / 1e12)
+    return dict(launches=n, avg_flops=flops / n, avg_us=ms * 1e3 / n, tflops=flops / (ms * 1e-3) / 1e12,
+                per_call=per_call)
 
 
 def cpu_baseline(args, seconds=20.0):

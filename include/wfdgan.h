@@ -36,6 +36,8 @@ int wfd_get_gemm_mode(void);
 
 /* Split count the library recommends for an MxNxK product (fills 256 CUs when the batch dimension is tiny). */
 int wfd_gemm_pick_splits(int M, int N, int K);
+/* ... for a given operand mode (the bf16-pipe core of modes 1 / 2 uses 128x128 tiles on large products) */
+int wfd_gemm_pick_splits_mode(int M, int N, int K, int mode);
 
 /* layout 0 (NT): P = A[M][K] * B[N][K]^T   -- nn.Linear forward (torch addmm), src/model.py:28-32,57-66,187-196
  * layout 1 (NN): P = A[M][K] * B[K][N]     -- input-gradient of nn.Linear: autograd.grad / backward,
@@ -53,6 +55,8 @@ int wfd_conv8_gemm_f32(const float* X, int Bn, int L, int Cin, int pad, const fl
 /* 1 when the conv entry points below run an (M = Bn*L, Cin, Cout) conv with the LDS-resident kernel (Cin = 32 on a long
  * sequence: input rows and the weight tile stay in LDS, no K split): take the fused single-launch form then */
 int wfd_conv8_direct(int M, int Cin, int Cout);
+/* ... for a given operand mode (modes 1 / 2: Cin, Cout in {32, 64} with at least 256 chunks of 128 rows) */
+int wfd_conv8_direct_mode(int M, int Cin, int Cout, int mode);
 
 /* The same contractions with the consumer's element-wise math fused into the store (single split: no slab round
  * trip, one launch less): epi 1 = wfd_ep_affine_act (scale/shift/act), epi 2 = wfd_ep_mul (D/dmode/scale, no second

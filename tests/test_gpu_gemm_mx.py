@@ -123,3 +123,46 @@ def test_mx_conv8(mode_guard, mode, cfg, pad):
     want = torch.relu(ref.permute(0, 2, 1).reshape(M, Cout) * scale.double() + shift.double())
     got = O.cpu().double()
     assert (got - want).abs().max().item() / want.abs().max().item() < TOL[mode]
+
+
+@pytest.mark.parametrize("mode", [1, 2])
+@pytest.mark.parametrize("cfg", [(24, 1400, 32, 32), (190, 175, 32, 64), (190, 175, 64, 32), (190, 175, 64, 64),
+                                 (1100, 33, 32, 32)])
+@pytest.mark.parametrize("pad", [3, 4])
+def test_mx_conv8_lds_resident(mode_guard, mode, cfg, pad):
+    """>= 256 chunks of 128 rows with Cin, Cout in {32, 64}: the LDS-resident conv kernel (weights as bf16 in LDS, input
+    rows loaded once); raw product, both fused stores, sample edges inside a chunk (L = 33), ragged last chunk."""
+    import torch.nn.functional as F
+    L = mode_guard
+    L.set_gemm_mode(mode)
+    Bn, Ln, Cin, Cout = cfg
+    M = Bn * Ln
+    assert L.conv8_direct_mode(M, Cin, Cout, mode) == (0 if (mode == 2 and Cin == 64 and Cout == 64) else 1)
+    g = torch.Generator().manual_seed(2)
+    x = torch.randn(Bn, Cin, Ln, generator=g)
+    w = torch.randn(Cout, Cin, 8, generator=g)
+    ref = F.conv1d(F.pad(x.double(), (pad, 7 - pad)), w.double()).permute(0, 2, 1).reshape(M, Cout)
+    xcl = x.permute(0, 2, 1).contiguous().to("cuda:0")
+    wp = w.permute(0, 2, 1).reshape(Cout, 8 * Cin).contiguous().to("cuda:0")
+    st = torch.cuda.current_stream().cuda_stream
+    P = torch.full((M, Cout), float("nan"), device="cuda:0")
+    L.conv8_gemm_f32(xcl.data_ptr(), Bn, Ln, Cin, pad, wp.data_ptr(), Cout, P.data_ptr(), Cout, M * Cout, 1, st)
+    torch.cuda.synchronize()
+    got = P.cpu().double()
+    assert torch.isfinite(got).all()
+    assert (got - ref).abs().max().item() / ref.abs().max().item() < TOL[mode]
+    scale, shift = torch.rand(Cout, generator=g) + 0.5, torch.randn(Cout, generator=g)
+    sd, hd = scale.to("cuda:0"), shift.to("cuda:0")
+    O = torch.full((M, Cout), float("nan"), device="cuda:0")
+    L.conv8_gemm_f32_fused(xcl.data_ptr(), Bn, Ln, Cin, pad, wp.data_ptr(), Cout, O.data_ptr(), Cout, 1, sd.data_ptr(),
+                           hd.data_ptr(), 2, 0, 0, 0, st)                     # affine + ELU
+    torch.cuda.synchronize()
+    want = F.elu(ref * scale.double() + shift.double())
+    assert (O.cpu().double() - want).abs().max().item() / want.abs().max().item() < TOL[mode]
+    D = torch.randn(M, Cout, generator=g)
+    Dd = D.to("cuda:0")
+    L.conv8_gemm_f32_fused(xcl.data_ptr(), Bn, Ln, Cin, pad, wp.data_ptr(), Cout, O.data_ptr(), Cout, 2, sd.data_ptr(), 0,
+                           0, Dd.data_ptr(), Cout, 2, st)                      # * [D > 0] * scale
+    torch.cuda.synchronize()
+    want = ref * (D > 0).double() * scale.double()
+    assert (O.cpu().double() - want).abs().max().item() / ref.abs().max().item() < TOL[mode]

@@ -10,15 +10,17 @@ dev = "cuda:0"
 st = torch.cuda.current_stream().cuda_stream
 S, C = 1401, 100
 shapes = [  # (name, layout, M, N, K, lda, ldb)
-    ("D fwd1 NT", 0, 128, 2048, 1501, 1504, 1501), ("D fwd2 NT", 0, 128, 1024, 2048, 2048, 2048),
+    ("D fwd1 NT", 0, 128, 2048, 1501, 1504, 1504), ("D fwd2 NT", 0, 128, 1024, 2048, 2048, 2048),
     ("D fwd3 NT", 0, 128, 512, 1024, 1024, 1024), ("chain3 NN", 1, 128, 1024, 512, 512, 1024),
-    ("chain2 NN", 1, 128, 2048, 1024, 1024, 2048), ("chain1 NN", 1, 128, 1401, 2048, 2048, 1501),
-    ("t1 NT", 0, 128, 2048, 1401, 1504, 1501), ("dW1 TN", 2, 2048, 1501, 256, 2048, 1504),
+    ("chain2 NN", 1, 128, 2048, 1024, 1024, 2048), ("chain1 NN", 1, 128, 1401, 2048, 2048, 1504),
+    ("t1 NT", 0, 128, 2048, 1401, 1504, 1504), ("dW1 TN", 2, 2048, 1501, 256, 2048, 1504),
     ("dW2 TN", 2, 1024, 2048, 256, 1024, 2048), ("dW3 TN", 2, 512, 1024, 256, 512, 1024),
     ("G fwd1 NT", 0, 64, 512, 600, 600, 600), ("G fwd2 NT", 0, 64, 1024, 512, 512, 512),
     ("G fwd3 NT", 0, 64, 2048, 1024, 1024, 1024), ("G fwd4 NT", 0, 64, 1401, 2048, 2048, 2048),
     ("dW8 TN", 2, 1401, 2048, 64, 1404, 2048), ("dh3 NN", 1, 64, 2048, 1401, 1404, 2048),
     ("sample L3 NT", 0, 8192, 2048, 1024, 1024, 1024), ("sample L4 NT", 0, 8192, 1401, 2048, 2048, 2048),
+    ("big chain2 NN", 1, 8192, 2048, 1024, 1024, 2048), ("big dW2 TN", 2, 1024, 2048, 8192, 1024, 2048),
+    ("big dW1 TN", 2, 2048, 1501, 8192, 2048, 1504),
 ]
 ws = torch.empty(1 << 28, device=dev)
 mode = int(sys.argv[1]) if len(sys.argv) > 1 else 0
@@ -31,7 +33,7 @@ for name, lay, M, N, K, lda, ldb in shapes:
     B = torch.randn(rb, ldb, device=dev)
     ldp = (N + 3) // 4 * 4
     res = []
-    for ns in sorted({1, 2, 4, 8, 16, L.gemm_pick_splits(M, N, K)}):
+    for ns in sorted({1, 2, 4, 8, 16, L.gemm_pick_splits_mode(M, N, K, mode)}):
         if ns * M * ldp > ws.numel() or (K + 31) // 32 < ns:
             continue
         for _ in range(3):
@@ -44,4 +46,4 @@ for name, lay, M, N, K, lda, ldb in shapes:
         torch.cuda.synchronize()
         us = e0.elapsed_time(e1) * 1e3 / 20
         res.append(f"ns={ns}: {us:6.1f}us {2.0*M*N*K/us/1e6:5.1f}TF")
-    print(f"{name:14s} M={M:5d} N={N:5d} K={K:5d} pick={L.gemm_pick_splits(M,N,K):2d} | " + " | ".join(res), flush=True)
+    print(f"{name:14s} M={M:5d} N={N:5d} K={K:5d} pick={L.gemm_pick_splits_mode(M,N,K,mode):2d} | " + " | ".join(res), flush=True)

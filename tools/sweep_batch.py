@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Large-batch sweep (BASELINE.json configs[3], fp32 part): whole-step throughput and GEMM-core TFLOP/s vs batch size
+"""Large-batch sweep (BASELINE.json configs[3]; --operands f32 | bf16 | bf16x3): whole-step throughput and GEMM-core TFLOP/s vs batch size
 and burst length.  GPU only.   python tools/sweep_batch.py [--L 1400 2500 5000] [--B 64 256 1024 4096]"""
 import argparse, json, os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -10,12 +10,13 @@ ap = argparse.ArgumentParser()
 ap.add_argument("--L", type=int, nargs="+", default=[1400])
 ap.add_argument("--B", type=int, nargs="+", default=[64, 256, 1024, 4096])
 ap.add_argument("--steps", type=int, default=30)
+ap.add_argument("--operands", default="f32", choices=["f32", "bf16", "bf16x3"])
 a = ap.parse_args()
 dev = torch.device("cuda:0")
 for L in a.L:
     for B in a.B:
         args = argparse.Namespace(seq_len=L + 1, classes=100, latent_dim=500, batch=B, inst=max(200, 2 * B // 100 + 1),
-                                  penalty="div", overlap=0, dp="weak")
+                                  penalty="div", overlap=0, dp="weak", operands=a.operands)
         eng, _ = bench.build_engine(args, 0, 1, dev)
         eng.capture_graphs()
         bench.run_steps(eng, 0, 6)
@@ -25,7 +26,7 @@ for L in a.L:
         torch.cuda.synchronize()
         dt = time.perf_counter() - t0
         roof = bench.gemm_roofline(eng, rep=4, rounds=2)
-        print(json.dumps(dict(L=L, B=B, it_per_s=a.steps / dt, samples_per_s=a.steps * B / dt,
+        print(json.dumps(dict(operands=a.operands, L=L, B=B, it_per_s=a.steps / dt, samples_per_s=a.steps * B / dt,
                               gemm_tflops=roof["tflops"], gemm_frac_of_f32_mfma_peak=roof["tflops"] / 157.3,
                               avg_us_per_gemm=roof["avg_us"])), flush=True)
         del eng

@@ -455,6 +455,7 @@ int g_gemm_mode = 0;
 }  // namespace
 
 int wfd_mx_launch(const GemmArgs& g, int layout, int splits, int terms, hipStream_t st);     // gemm_mx.hip
+bool wfd_mx_conv_direct(int M, int Cin, int Cout, int terms);
 
 extern "C" {
 
@@ -478,9 +479,37 @@ int wfd_gemm_pick_splits(int M, int N, int K) {
     return s;
 }
 
+// The same for a given operand mode (wfd_set_gemm_mode): the bf16-pipe core (modes 1, 2) switches to 128x128 tiles once
+// they fill the chip, so mid-sized products are split for THAT tile (about 512 workgroups, >= 2 of its k-tiles per split).
+int wfd_gemm_pick_splits_mode(int M, int N, int K, int mode) {
+    if (mode == 0) return wfd_gemm_pick_splits(M, N, K);
+    const long t128 = (long)cdiv(M, 128) * cdiv(N, 128);
+    if (t128 >= 256) return 1;
+    if (t128 >= 64) {
+        // two 128x128 workgroups fit a CU: a "wave" is 512 of them.  Take the split count whose grid wastes the least
+        // of its last wave (smallest on ties), with at least four 64-deep k-tiles per split.
+        const int ktiles = cdiv(K, 64);
+        int smax = ktiles / 4;
+        if (smax > 16) smax = 16;
+        int best = 1;
+        double best_eff = 0.0;
+        for (int s = cdiv(512, t128); s <= smax; ++s) {
+            const double w = (double)t128 * s / 512.0;
+            const double eff = w / (double)cdiv(t128 * s, 512);
+            if (eff > best_eff + 0.02) { best_eff = eff; best = s; }
+        }
+        return best;
+    }
+    return wfd_gemm_pick_splits(M, N, K);
+}
+
 // 1 when the fused conv entry points run a (Bn*L, Cin, Cout) conv with the LDS-resident kernel (no K split needed: the
 // caller should take the fused single-launch path whatever wfd_gemm_pick_splits says)
 int wfd_conv8_direct(int M, int Cin, int Cout) { return use_conv8_c32(M, Cin, Cout) ? 1 : 0; }
+int wfd_conv8_direct_mode(int M, int Cin, int Cout, int mode) {
+    if (mode == 0) return wfd_conv8_direct(M, Cin, Cout);
+    return wfd_mx_conv_direct(M, Cin, Cout, mode) ? 1 : 0;
+}
 
 // layout: 0 = NT, 1 = NN, 2 = TN.  P receives `splits` slabs of M x ldp floats, slab_stride floats apart.
 int wfd_gemm_f32(int layout, const float* A, int lda, const float* B, int ldb, float* P, int ldp, long slab_stride,

@@ -12,11 +12,13 @@
 // Nothing in HBM changes: activations, weights, slabs and every epilogue stay fp32, so a step plan runs on either
 // core unmodified (wfd_set_gemm_mode).
 //
-// Tile 64x64x64 per 256-thread workgroup, 2x2 waves of one 32x32 accumulator.  Staging is global -> registers ->
+// Tiles: 64x64x64 per 256-thread workgroup (2x2 waves of one 32x32 accumulator; the batch-64 step, with split-K), or
+// 128x128 (2x2 waves of 2x2 accumulators) once such tiles alone fill the chip.  Staging is global -> registers ->
 // convert -> LDS, double buffered, one barrier per k-tile.  LDS images:
-//   k-contiguous operand ([rows][K] in HBM):  [row][72] bf16 (144-B rows: nine 16-B slots, so the ds_read_b128
-//       fragment reads of 32 consecutive rows are conflict-free); lane (i, h) of k-step s reads k = 16 s + 8 h .. + 7.
-//   m-contiguous operand ([K][rows] in HBM):  [k][64] bf16 as loaded; the fragment (8 consecutive k of one row per
+//   k-contiguous operand ([rows][K] in HBM):  [row][KT + 8] bf16 (an odd number of 16-B slots per row, so the
+//       ds_read_b128 fragment reads of 32 consecutive rows are conflict-free); lane (i, h) of k-step s reads
+//       k = 16 s + 8 h .. + 7.
+//   m-contiguous operand ([K][rows] in HBM):  [k][T (+16)] bf16 as loaded; the fragment (8 consecutive k of one row per
 //       lane) comes from two ds_read_b64_tr_b16 (hardware transpose: a 16-lane group reads a 4 x 16 block and lane c
 //       receives column c), so no transposing store and no second image is needed.
 #include "gemm_args.h"
@@ -27,21 +29,32 @@ typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef short s16x4 __attribute__((ext_vector_type(4)));
 
-constexpr int XM = 64, XN = 64, XK = 64, XT = 256;
-constexpr int RSK = XK + 8;          // row stride (elements) of a k-contiguous image
-constexpr int RSM = 64;              // row stride of an m-contiguous image [k][64]
-constexpr int IMG = 64 * RSK;        // elements reserved per image (>= 64 * RSM)
+constexpr int XT = 256;
 
-// ---- global -> registers: 4 float4 per thread per operand tile ---------------------------------------------------
-template <bool KC, bool IM2COL>
-__device__ __forceinline__ void mx_load(float4 (&r)[4], const float* __restrict__ G, int ld, int row0, int nrows, int k0,
-                                        int kend, int tid, int convL, int convCin, int convPad) {
-    const int q = tid & 15, w = tid >> 4;
+// Tile geometry: T x T outputs per 256-thread workgroup (T = 64: 2x2 waves of one 32x32 accumulator; T = 128: 2x2
+// waves of 2x2 accumulators -- every fragment read feeds two MFMAs per term), KT-deep k-tiles.
+template <int T, int KT>
+struct Geo {
+    static constexpr int RSK = KT + 8;        // row stride (elements) of a k-contiguous image [T][KT + 8]
+    static constexpr int RSM = T == 64 ? 64 : T + 16;   // row stride of an m-contiguous image [KT][RSM]; the 4 x 16 blocks of
+                                              // a transposed read are 2-way conflicted at these strides (a perfect tiling
+                                              // needs T + 32, which costs a workgroup per CU in LDS: measured slower)
+    static constexpr int IMG_K = T * RSK, IMG_M = KT * RSM;
+    static constexpr int NLD = T * KT / 4 / XT;   // float4 per thread per operand tile
+};
+
+// ---- global -> registers ---------------------------------------------------------------------------------------
+template <int T, int KT, bool KC, bool IM2COL, int NLD>
+__device__ __forceinline__ void mx_load(float4 (&r)[NLD], const float* __restrict__ G, int ld, int row0,
+                                        int nrows, int k0, int kend, int tid, int convL, int convCin, int convPad) {
+    constexpr int QK = KT / 4, QM = T / 4;
+    static_assert(NLD == Geo<T, KT>::NLD, "staging registers per thread");
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
+    for (int j = 0; j < NLD; ++j) {
         float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
         if constexpr (KC) {
-            const int gr = row0 + w + 16 * j, gk = k0 + 4 * q;
+            const int q = tid % QK, w = tid / QK;
+            const int gr = row0 + w + (XT / QK) * j, gk = k0 + 4 * q;
             bool ok = gr < nrows && gk < kend;
             long off = (long)gr * ld + gk;
             if constexpr (IM2COL) {
@@ -59,7 +72,8 @@ __device__ __forceinline__ void mx_load(float4 (&r)[4], const float* __restrict_
                 }
             }
         } else {
-            const int gk = k0 + w + 16 * j, gc = row0 + 4 * q;
+            const int q = tid % QM, w = tid / QM;
+            const int gk = k0 + w + (XT / QM) * j, gc = row0 + 4 * q;
             if (gk < kend && gc < nrows) {
                 const long off = (long)gk * ld + gc;
                 if (gc + 3 < nrows) {
@@ -76,14 +90,17 @@ __device__ __forceinline__ void mx_load(float4 (&r)[4], const float* __restrict_
 }
 
 // ---- registers -> bf16 (hi [, lo]) -> LDS --------------------------------------------------------------------------
-template <bool KC, int TERMS>
-__device__ __forceinline__ void mx_store(const float4 (&r)[4], __bf16* __restrict__ S, int tid) {
-    const int q = tid & 15, w = tid >> 4;
+template <int T, int KT, bool KC, int TERMS, int NLD>
+__device__ __forceinline__ void mx_store(const float4 (&r)[NLD], __bf16* __restrict__ S, int tid) {
+    using G_ = Geo<T, KT>;
+    constexpr int QK = KT / 4, QM = T / 4;
+    constexpr int IMG = KC ? G_::IMG_K : G_::IMG_M;
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
+    for (int j = 0; j < G_::NLD; ++j) {
         const f32x4 x = {r[j].x, r[j].y, r[j].z, r[j].w};
         const bf16x4 hi = __builtin_convertvector(x, bf16x4);
-        const int off = KC ? (w + 16 * j) * RSK + 4 * q : (w + 16 * j) * RSM + 4 * q;
+        const int off = KC ? (tid / QK + (XT / QK) * j) * G_::RSK + 4 * (tid % QK)
+                           : (tid / QM + (XT / QM) * j) * G_::RSM + 4 * (tid % QM);
         *reinterpret_cast<bf16x4*>(S + off) = hi;
         if constexpr (TERMS == 2) {
             const f32x4 res = x - __builtin_convertvector(hi, f32x4);
@@ -94,106 +111,285 @@ __device__ __forceinline__ void mx_store(const float4 (&r)[4], __bf16* __restric
 
 // fragment of k-step s (16 deep) for the 32 rows starting at r0: lane (i = lane & 31, h = lane >> 5) gets
 // k = 16 s + 8 h + 0..7 of row r0 + i
-template <bool KC>
+template <int T, int KT, bool KC>
 __device__ __forceinline__ bf16x8 mx_frag(const __bf16* __restrict__ S, int r0, int s, int lane) {
+    using G_ = Geo<T, KT>;
     if constexpr (KC) {
-        return *reinterpret_cast<const bf16x8*>(S + (r0 + (lane & 31)) * RSK + 16 * s + 8 * (lane >> 5));
+        return *reinterpret_cast<const bf16x8*>(S + (r0 + (lane & 31)) * G_::RSK + 16 * s + 8 * (lane >> 5));
     } else {
         // 16-lane group g2 covers rows r0 + 16 g2 .. + 15; lane 4 qq + p of the group addresses k-row qq, columns 4 p .. 4 p + 3
         const int li = lane & 15, qq = li >> 2, p = li & 3, g2 = (lane >> 4) & 1, h = lane >> 5;
-        const __bf16* base = S + (16 * s + 8 * h + qq) * RSM + r0 + 16 * g2 + 4 * p;
+        const __bf16* base = S + (16 * s + 8 * h + qq) * G_::RSM + r0 + 16 * g2 + 4 * p;
         typedef s16x4 __attribute__((address_space(3))) * lds_s16x4;
         const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4)(base));
-        const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4)(base + 4 * RSM));
+        const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4)(base + 4 * G_::RSM));
         union { struct { s16x4 a, b; } s; bf16x8 v; } u;
         u.s.a = lo; u.s.b = hi;
         return u.v;
     }
 }
 
-template <bool AKC, bool BKC, bool IM2COL, int TERMS, bool EPI>
-__global__ __launch_bounds__(XT) void gemm_mx_kernel(GemmArgs g, int kchunk) {
+template <int T, int KT, bool AKC, bool BKC, bool IM2COL, int TERMS, bool EPI>
+__global__ __launch_bounds__(XT) void gemm_mx_kernel(GemmArgs g, int kchunk, int gx, int gy) {
     extern __shared__ __attribute__((aligned(16))) __bf16 smem[];
+    using G_ = Geo<T, KT>;
+    constexpr int IMG_A = AKC ? G_::IMG_K : G_::IMG_M, IMG_B = BKC ? G_::IMG_K : G_::IMG_M;
     // buffer c: [A hi | A lo | B hi | B lo] images (lo only with TERMS = 2)
-    constexpr int BUF = 2 * TERMS * IMG;
+    constexpr int BUF = TERMS * (IMG_A + IMG_B);
+    constexpr int FR = T / 64;                    // 32x32 accumulators per wave along each dimension
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1, i = lane & 31, h = lane >> 5;
-    const int m0 = blockIdx.y * XM, n0 = blockIdx.x * XN, z = blockIdx.z;
+    // tile order: ids b and b + 8 share an XCD (round-robin dispatch); give each XCD a contiguous run of tiles so that
+    // the operand panels its workgroups share stay in its L2 (speed only)
+    int bid = blockIdx.x;
+    if (gx * gy >= 256) {         // small grids keep the dispatch order: the two row tiles of a weight panel share an XCD
+        const int nb = gx * gy, xcd = bid & 7, qd = nb >> 3, rm = nb & 7;
+        bid = (xcd < rm ? xcd * (qd + 1) : rm * (qd + 1) + (xcd - rm) * qd) + (bid >> 3);
+    }
+    const int m0 = (bid / gx) * T, n0 = (bid % gx) * T, z = blockIdx.z;
     const int kbeg = z * kchunk;
     const int kend = min(g.K, kbeg + kchunk);
-    const int nk = (kend > kbeg) ? (kend - kbeg + XK - 1) / XK : 0;
+    const int nk = (kend > kbeg) ? (kend - kbeg + KT - 1) / KT : 0;
 
-    f32x16 acc;
+    f32x16 acc[FR][FR];
 #pragma unroll
-    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+    for (int a = 0; a < FR; ++a)
+#pragma unroll
+        for (int b = 0; b < FR; ++b)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
 
-    float4 ra[4], rb[4];
+    float4 ra[G_::NLD], rb[G_::NLD];
     if (nk > 0) {
-        mx_load<AKC, IM2COL>(ra, g.A, g.lda, m0, g.M, kbeg, kend, tid, g.convL, g.convCin, g.convPad);
-        mx_load<BKC, false>(rb, g.B, g.ldb, n0, g.N, kbeg, kend, tid, 0, 0, 0);
-        mx_store<AKC, TERMS>(ra, smem, tid);
-        mx_store<BKC, TERMS>(rb, smem + TERMS * IMG, tid);
+        mx_load<T, KT, AKC, IM2COL>(ra, g.A, g.lda, m0, g.M, kbeg, kend, tid, g.convL, g.convCin, g.convPad);
+        mx_load<T, KT, BKC, false>(rb, g.B, g.ldb, n0, g.N, kbeg, kend, tid, 0, 0, 0);
+        mx_store<T, KT, AKC, TERMS>(ra, smem, tid);
+        mx_store<T, KT, BKC, TERMS>(rb, smem + TERMS * IMG_A, tid);
     }
     __syncthreads();
     int cur = 0;
     for (int kt = 0; kt < nk; ++kt) {
         const bool more = kt + 1 < nk;
         if (more) {
-            const int k0 = kbeg + (kt + 1) * XK;
-            mx_load<AKC, IM2COL>(ra, g.A, g.lda, m0, g.M, k0, kend, tid, g.convL, g.convCin, g.convPad);
-            mx_load<BKC, false>(rb, g.B, g.ldb, n0, g.N, k0, kend, tid, 0, 0, 0);
+            const int k0 = kbeg + (kt + 1) * KT;
+            mx_load<T, KT, AKC, IM2COL>(ra, g.A, g.lda, m0, g.M, k0, kend, tid, g.convL, g.convCin, g.convPad);
+            mx_load<T, KT, BKC, false>(rb, g.B, g.ldb, n0, g.N, k0, kend, tid, 0, 0, 0);
         }
         const __bf16* a_s = smem + cur * BUF;
-        const __bf16* b_s = a_s + TERMS * IMG;
+        const __bf16* b_s = a_s + TERMS * IMG_A;
 #pragma unroll
-        for (int s = 0; s < 4; ++s) {
-            const bf16x8 ah = mx_frag<AKC>(a_s, wm * 32, s, lane);
-            const bf16x8 bh = mx_frag<BKC>(b_s, wn * 32, s, lane);
-            if constexpr (TERMS == 2) {
-                const bf16x8 al = mx_frag<AKC>(a_s + IMG, wm * 32, s, lane);
-                const bf16x8 bl = mx_frag<BKC>(b_s + IMG, wn * 32, s, lane);
-                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh, acc, 0, 0, 0);
-                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl, acc, 0, 0, 0);
+        for (int s = 0; s < KT / 16; ++s) {
+            bf16x8 ah[FR], bh[FR], al[FR], bl[FR];
+#pragma unroll
+            for (int t = 0; t < FR; ++t) {
+                ah[t] = mx_frag<T, KT, AKC>(a_s, wm * (T / 2) + 32 * t, s, lane);
+                bh[t] = mx_frag<T, KT, BKC>(b_s, wn * (T / 2) + 32 * t, s, lane);
+                if constexpr (TERMS == 2) {
+                    al[t] = mx_frag<T, KT, AKC>(a_s + IMG_A, wm * (T / 2) + 32 * t, s, lane);
+                    bl[t] = mx_frag<T, KT, BKC>(b_s + IMG_B, wn * (T / 2) + 32 * t, s, lane);
+                }
             }
-            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh, acc, 0, 0, 0);
+#pragma unroll
+            for (int a = 0; a < FR; ++a)
+#pragma unroll
+                for (int b = 0; b < FR; ++b) {
+                    if constexpr (TERMS == 2) {
+                        acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[a], bh[b], acc[a][b], 0, 0, 0);
+                        acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[a], bl[b], acc[a][b], 0, 0, 0);
+                    }
+                    acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[a], bh[b], acc[a][b], 0, 0, 0);
+                }
         }
         if (more) {
-            mx_store<AKC, TERMS>(ra, smem + (cur ^ 1) * BUF, tid);
-            mx_store<BKC, TERMS>(rb, smem + (cur ^ 1) * BUF + TERMS * IMG, tid);
+            mx_store<T, KT, AKC, TERMS>(ra, smem + (cur ^ 1) * BUF, tid);
+            mx_store<T, KT, BKC, TERMS>(rb, smem + (cur ^ 1) * BUF + TERMS * IMG_A, tid);
         }
         __syncthreads();
         cur ^= 1;
     }
 
-    // C/D map of the 32x32 accumulator: col = lane & 31, row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)
+    // C/D map of a 32x32 accumulator: col = lane & 31, row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)
     float* P = g.P + (long)z * g.slab_stride;
-    const int col = n0 + wn * 32 + i;
-    if (col < g.N) {
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int row = m0 + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
-            if (row < g.M) {
-                if constexpr (EPI) P[(long)row * g.ldp + col] = epi_apply(g, acc[r], row, col);
-                else P[(long)row * g.ldp + col] = acc[r];
+    for (int a = 0; a < FR; ++a)
+#pragma unroll
+        for (int b = 0; b < FR; ++b) {
+            const int col = n0 + wn * (T / 2) + 32 * b + i;
+            if (col >= g.N) continue;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = m0 + wm * (T / 2) + 32 * a + (r & 3) + 8 * (r >> 2) + 4 * h;
+                if (row >= g.M) continue;
+                if constexpr (EPI) P[(long)row * g.ldp + col] = epi_apply(g, acc[a][b][r], row, col);
+                else P[(long)row * g.ldp + col] = acc[a][b][r];
+            }
+        }
+}
+
+template <int T, int KT, bool AKC, bool BKC, bool IM2COL, int TERMS, bool EPI>
+int mx_launch4(const GemmArgs& g, int splits, hipStream_t st) {
+    using G_ = Geo<T, KT>;
+    static bool attr = false;
+    const size_t lds = (size_t)2 * TERMS * ((AKC ? G_::IMG_K : G_::IMG_M) + (BKC ? G_::IMG_K : G_::IMG_M)) * sizeof(__bf16);
+    if (!attr) {
+        (void)hipFuncSetAttribute((const void*)gemm_mx_kernel<T, KT, AKC, BKC, IM2COL, TERMS, EPI>,
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        attr = true;
+    }
+    const int kchunk = g.ktiles_per_split * 32;       // ktiles_per_split counts 32-deep tiles (gemm.hip's BK)
+    const int gx = cdiv(g.N, T), gy = cdiv(g.M, T);
+    dim3 grid(gx * gy, 1, splits), block(XT);
+    hipLaunchKernelGGL((gemm_mx_kernel<T, KT, AKC, BKC, IM2COL, TERMS, EPI>), grid, block, lds, st, g, kchunk, gx, gy);
+    WFD_CHECK_LAUNCH();
+    return WFD_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// k=8 "SAME" conv over a long channels-last sequence with few channels (the DF observer's first two blocks: Cin, Cout in
+// {32, 64}, M = B*L rows): on the bf16 pipe the arithmetic is negligible and the implicit-GEMM form above is bound by
+// re-reading every activation row eight times (once per tap).  Here a workgroup keeps the whole weight matrix
+// [Cout][8*Cin] in LDS as bf16 for its lifetime and walks `cpw` consecutive chunks of 128 output rows: a chunk's
+// 128 + 7 input rows are loaded once (contiguous, register-prefetched one chunk ahead), converted, and the A fragment of
+// tap t is the same LDS tile read t rows further down.  HBM traffic = input + output once: an HBM-bound kernel.
+// Wave w owns rows 32 w .. 32 w + 31 of the chunk and all Cout columns.  Sample edges are masked per lane.
+constexpr int CV_ROWS = 128;
+
+template <int CIN, int COUT, int TERMS>
+struct ConvGeo {
+    static constexpr int WS = 8 * CIN + 8, XS = CIN + 8;          // bf16 row strides: odd numbers of 16-B slots
+    static constexpr int W_IMG = COUT * WS, X_IMG = (CV_ROWS + 7) * XS;
+    static constexpr int XLD = ((CV_ROWS + 7) * CIN / 4 + XT - 1) / XT;   // float4 per thread per chunk
+    static constexpr size_t LDS = (size_t)TERMS * (W_IMG + X_IMG) * sizeof(__bf16);
+};
+
+template <int TERMS>
+__device__ __forceinline__ void cv_put(__bf16* __restrict__ S, int img, int off, const float4& v) {
+    const f32x4 x = {v.x, v.y, v.z, v.w};
+    const bf16x4 hi = __builtin_convertvector(x, bf16x4);
+    *reinterpret_cast<bf16x4*>(S + off) = hi;
+    if constexpr (TERMS == 2) {
+        const f32x4 res = x - __builtin_convertvector(hi, f32x4);
+        *reinterpret_cast<bf16x4*>(S + img + off) = __builtin_convertvector(res, bf16x4);
+    }
+}
+
+template <int CIN, int COUT, int TERMS, bool EPI>
+__global__ __launch_bounds__(XT) void conv8_lds_mx_kernel(GemmArgs g, int cpw, int nchunks) {
+    extern __shared__ __attribute__((aligned(16))) __bf16 smem[];
+    using C_ = ConvGeo<CIN, COUT, TERMS>;
+    __bf16* ws = smem;                            // [TERMS][COUT][WS]
+    __bf16* xs = smem + TERMS * C_::W_IMG;        // [TERMS][135][XS]
+    constexpr int Q = CIN / 4, NA = COUT / 32;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, i = lane & 31, h = lane >> 5;
+    const int pad = g.convPad, L = g.convL;
+    const int c0 = blockIdx.x * cpw, c1 = min(nchunks, c0 + cpw);
+
+    for (int c = tid; c < COUT * 2 * CIN; c += XT) {           // weights: COUT rows x 8*CIN floats, float4 granules
+        const int r = c / (2 * CIN), q = c % (2 * CIN);
+        cv_put<TERMS>(ws, C_::W_IMG, r * C_::WS + 4 * q, *reinterpret_cast<const float4*>(g.B + (long)r * (8 * CIN) + 4 * q));
+    }
+    float4 rx[C_::XLD];
+    auto load_x = [&](int chunk) {
+        const long base = (long)chunk * CV_ROWS - pad;
+#pragma unroll
+        for (int j = 0; j < C_::XLD; ++j) {
+            const int c = tid + XT * j, r = c / Q, q = c % Q;
+            const long src = base + r;
+            rx[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (c < (CV_ROWS + 7) * Q && src >= 0 && src < g.M) rx[j] = *reinterpret_cast<const float4*>(g.A + src * CIN + 4 * q);
+        }
+    };
+    if (c0 < c1) load_x(c0);
+    for (int chunk = c0; chunk < c1; ++chunk) {
+        __syncthreads();                           // the previous chunk's fragment reads are done (and the weights are in)
+#pragma unroll
+        for (int j = 0; j < C_::XLD; ++j) {
+            const int c = tid + XT * j, r = c / Q, q = c % Q;
+            if (c < (CV_ROWS + 7) * Q) cv_put<TERMS>(xs, C_::X_IMG, r * C_::XS + 4 * q, rx[j]);
+        }
+        __syncthreads();
+        if (chunk + 1 < c1) load_x(chunk + 1);
+
+        const int m0 = chunk * CV_ROWS;
+        const int mrow = m0 + wave * 32 + i;       // the output row whose A values this lane feeds
+        const int l = mrow < g.M ? mrow % L : -(1 << 20);
+        f32x16 acc[NA];
+#pragma unroll
+        for (int b = 0; b < NA; ++b)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[b][r] = 0.f;
+#pragma unroll
+        for (int t = 0; t < 8; ++t) {
+            const bool ok = (unsigned)(l + t - pad) < (unsigned)L;
+            const __bf16* ap = xs + (wave * 32 + i + t) * C_::XS + 8 * h;
+            const __bf16* bp = ws + i * C_::WS + t * CIN + 8 * h;
+#pragma unroll
+            for (int s = 0; s < CIN / 16; ++s) {
+                bf16x8 ah = *reinterpret_cast<const bf16x8*>(ap + 16 * s), al;
+                if constexpr (TERMS == 2) al = *reinterpret_cast<const bf16x8*>(ap + C_::X_IMG + 16 * s);
+                if (!ok) {
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) { ah[e] = (__bf16)0.f; if constexpr (TERMS == 2) al[e] = (__bf16)0.f; }
+                }
+#pragma unroll
+                for (int b = 0; b < NA; ++b) {
+                    const bf16x8 bh = *reinterpret_cast<const bf16x8*>(bp + 32 * b * C_::WS + 16 * s);
+                    if constexpr (TERMS == 2) {
+                        const bf16x8 bl = *reinterpret_cast<const bf16x8*>(bp + C_::W_IMG + 32 * b * C_::WS + 16 * s);
+                        acc[b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh, acc[b], 0, 0, 0);
+                        acc[b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl, acc[b], 0, 0, 0);
+                    }
+                    acc[b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh, acc[b], 0, 0, 0);
+                }
+            }
+        }
+#pragma unroll
+        for (int b = 0; b < NA; ++b) {
+            const int col = 32 * b + i;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = m0 + wave * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+                if (row < g.M) {
+                    if constexpr (EPI) g.P[(long)row * g.ldp + col] = epi_apply(g, acc[b][r], row, col);
+                    else g.P[(long)row * g.ldp + col] = acc[b][r];
+                }
             }
         }
     }
 }
 
-template <bool AKC, bool BKC, bool IM2COL, int TERMS, bool EPI>
-int mx_launch3(const GemmArgs& g, int splits, hipStream_t st) {
+template <int CIN, int COUT, int TERMS, bool EPI>
+int cv_launch2(const GemmArgs& g, hipStream_t st) {
+    using C_ = ConvGeo<CIN, COUT, TERMS>;
     static bool attr = false;
-    const size_t lds = (size_t)2 * 2 * TERMS * IMG * sizeof(__bf16);
     if (!attr) {
-        (void)hipFuncSetAttribute((const void*)gemm_mx_kernel<AKC, BKC, IM2COL, TERMS, EPI>,
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        (void)hipFuncSetAttribute((const void*)conv8_lds_mx_kernel<CIN, COUT, TERMS, EPI>,
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)C_::LDS);
         attr = true;
     }
-    const int kchunk = g.ktiles_per_split * 32;       // ktiles_per_split counts 32-deep tiles (gemm.hip's BK)
-    dim3 grid(cdiv(g.N, XN), cdiv(g.M, XM), splits), block(XT);
-    hipLaunchKernelGGL((gemm_mx_kernel<AKC, BKC, IM2COL, TERMS, EPI>), grid, block, lds, st, g, kchunk);
+    const int nchunks = cdiv(g.M, CV_ROWS);
+    int cpw = nchunks / 1024;                     // amortise the weight staging once the chip is covered four times over
+    if (cpw < 1) cpw = 1;
+    if (cpw > 8) cpw = 8;
+    hipLaunchKernelGGL((conv8_lds_mx_kernel<CIN, COUT, TERMS, EPI>), dim3(cdiv(nchunks, cpw)), dim3(XT), C_::LDS, st, g, cpw,
+                       nchunks);
     WFD_CHECK_LAUNCH();
     return WFD_OK;
+}
+
+template <int CIN, int COUT>
+int cv_launch(const GemmArgs& g, int terms, hipStream_t st) {
+    if (terms == 1) return g.epi ? cv_launch2<CIN, COUT, 1, true>(g, st) : cv_launch2<CIN, COUT, 1, false>(g, st);
+    if constexpr (CIN == 64 && COUT == 64) return WFD_ERR_ARG;         // two weight images do not fit in LDS
+    else return g.epi ? cv_launch2<CIN, COUT, 2, true>(g, st) : cv_launch2<CIN, COUT, 2, false>(g, st);
+}
+
+template <bool AKC, bool BKC, bool IM2COL, int TERMS, bool EPI>
+int mx_launch3(const GemmArgs& g, int splits, hipStream_t st) {
+    // 128x128 tiles once they alone fill the chip (large-batch steps, bulk sampling); 64x64 with split-K below that
+    if ((long)cdiv(g.M, 128) * cdiv(g.N, 128) * splits >= 256)
+        return mx_launch4<128, TERMS == 2 ? 32 : 64, AKC, BKC, IM2COL, TERMS, EPI>(g, splits, st);
+    return mx_launch4<64, 64, AKC, BKC, IM2COL, TERMS, EPI>(g, splits, st);
 }
 
 template <bool AKC, bool BKC, bool IM2COL>
@@ -211,7 +407,17 @@ int mx_launch2(const GemmArgs& g, int splits, int terms, hipStream_t st) {
 // layout: 0 NT, 1 NN, 2 TN, 3 NT with the A operand read as the im2col matrix of a k=8 conv.  terms: 1 bf16, 2 bf16x3.
 // Requires 16-byte aligned operands with leading dimensions that are multiples of 4 floats (the caller falls back to
 // the f32-operand core otherwise).
+bool wfd_mx_conv_direct(int M, int Cin, int Cout, int terms) {
+    if (!((Cin == 32 || Cin == 64) && (Cout == 32 || Cout == 64))) return false;
+    if (terms == 2 && Cin == 64 && Cout == 64) return false;
+    return cdiv(M, CV_ROWS) >= 256;               // enough 128-row chunks to give every CU one
+}
+
 int wfd_mx_launch(const GemmArgs& g, int layout, int splits, int terms, hipStream_t st) {
+    if (layout == 3 && splits == 1 && wfd_mx_conv_direct(g.M, g.convCin, g.N, terms) && g.ldb == 8 * g.convCin) {
+        if (g.convCin == 32) return g.N == 32 ? cv_launch<32, 32>(g, terms, st) : cv_launch<32, 64>(g, terms, st);
+        return g.N == 32 ? cv_launch<64, 32>(g, terms, st) : cv_launch<64, 64>(g, terms, st);
+    }
     switch (layout) {
         case 0: return mx_launch2<true, true, false>(g, splits, terms, st);
         case 1: return mx_launch2<true, false, false>(g, splits, terms, st);

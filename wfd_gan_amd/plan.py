@@ -65,6 +65,9 @@ class Plan:
     def ws_floats(self):
         return self.ws_lane[self.lane].numel()
 
+    def pick_splits(self, M: int, N: int, K: int) -> int:
+        return self.L.gemm_pick_splits_mode(M, N, K, self.gemm_mode)
+
     # -- generic ------------------------------------------------------------------------------------------
     def add(self, fn, *args):
         self.calls.append((fn, args, self.lane))
@@ -158,10 +161,20 @@ class Plan:
              splits: Optional[int] = None) -> Slabs:
         """Raw product into the slab workspace (or straight into ``out`` with splits = 1)."""
         if out is not None:
-            self.add(self.L.gemm_f32, layout, ptr(A), lda, ptr(B), ldb, ptr(out), ldp, 0, M, N, K, 1)
+            # a long contraction that alone cannot fill the chip (weight gradients of a large batch: K = rows of the
+            # batch) is split over K into slabs and summed into `out`; short ones go straight into `out`
+            ns = self.pick_splits(M, N, K) if K >= 1024 else 1
+            lds = rup(N, 4)
+            while ns > 1 and ns * M * lds > self.ws_floats:
+                ns -= 1
+            if ns > 1:
+                self.add(self.L.gemm_f32, layout, ptr(A), lda, ptr(B), ldb, ptr(self.ws), lds, M * lds, M, N, K, ns)
+                self.affine_act(Slabs(ptr(self.ws), ns, M * lds, lds, M, N), None, None, ACT_NONE, out, ldp)
+            else:
+                self.add(self.L.gemm_f32, layout, ptr(A), lda, ptr(B), ldb, ptr(out), ldp, 0, M, N, K, 1)
             return Slabs(ptr(out), 1, 0, ldp, M, N)
         ldp = rup(N, 4)
-        ns = splits or self.L.gemm_pick_splits(M, N, K)
+        ns = splits or self.pick_splits(M, N, K)
         ss = M * ldp
         while ns > 1 and ns * ss > self.ws_floats:
             ns -= 1
@@ -173,7 +186,7 @@ class Plan:
     def conv8(self, X, Bn: int, L: int, Cin: int, pad: int, Wp, Cout: int) -> Slabs:
         M, K = Bn * L, 8 * Cin
         ldp = rup(Cout, 4)
-        ns = self.L.gemm_pick_splits(M, Cout, K)
+        ns = self.pick_splits(M, Cout, K)
         ss = M * ldp
         while ns > 1 and ns * ss > self.ws_floats:
             ns -= 1
@@ -184,28 +197,28 @@ class Plan:
 
     # -- contraction + element-wise consumer: fused into one launch when a single split fills the chip ------------
     def gemm_affine(self, layout, A, lda, B, ldb, M, N, K, scale, shift, act, out, ldo):
-        if self.L.gemm_pick_splits(M, N, K) == 1:
+        if self.pick_splits(M, N, K) == 1:
             self.add(self.L.gemm_f32_fused, layout, ptr(A), lda, ptr(B), ldb, ptr(out), ldo, M, N, K, 1, ptr(scale),
                      ptr(shift), act, 0, 0, 0)
         else:
             self.affine_act(self.gemm(layout, A, lda, B, ldb, M, N, K), scale, shift, act, out, ldo)
 
     def gemm_mul(self, layout, A, lda, B, ldb, M, N, K, D, ldd, dmode, colscale, out, ldo):
-        if self.L.gemm_pick_splits(M, N, K) == 1:
+        if self.pick_splits(M, N, K) == 1:
             self.add(self.L.gemm_f32_fused, layout, ptr(A), lda, ptr(B), ldb, ptr(out), ldo, M, N, K, 2, ptr(colscale),
                      0, 0, ptr(D), ldd, dmode)
         else:
             self.mul(self.gemm(layout, A, lda, B, ldb, M, N, K), D, ldd, dmode, colscale, None, out, None, ldo)
 
     def conv8_affine(self, X, Bn, L, Cin, pad, Wp, Cout, scale, shift, act, out):
-        if self.L.gemm_pick_splits(Bn * L, Cout, 8 * Cin) == 1 or self.L.conv8_direct(Bn * L, Cin, Cout):
+        if self.pick_splits(Bn * L, Cout, 8 * Cin) == 1 or self.L.conv8_direct_mode(Bn * L, Cin, Cout, self.gemm_mode):
             self.add(self.L.conv8_gemm_f32_fused, ptr(X), Bn, L, Cin, pad, ptr(Wp), Cout, ptr(out), Cout, 1, ptr(scale),
                      ptr(shift), act, 0, 0, 0)
         else:
             self.affine_act(self.conv8(X, Bn, L, Cin, pad, Wp, Cout), scale, shift, act, out, Cout)
 
     def conv8_mul(self, X, Bn, L, Cin, pad, Wp, Cout, D, ldd, dmode, colscale, out):
-        if self.L.gemm_pick_splits(Bn * L, Cout, 8 * Cin) == 1 or self.L.conv8_direct(Bn * L, Cin, Cout):
+        if self.pick_splits(Bn * L, Cout, 8 * Cin) == 1 or self.L.conv8_direct_mode(Bn * L, Cin, Cout, self.gemm_mode):
             self.add(self.L.conv8_gemm_f32_fused, ptr(X), Bn, L, Cin, pad, ptr(Wp), Cout, ptr(out), Cout, 2,
                      ptr(colscale), 0, 0, ptr(D), ldd, dmode)
         else:
