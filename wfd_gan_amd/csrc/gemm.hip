@@ -500,7 +500,9 @@ int wfd_gemm_pick_splits_mode(int M, int N, int K, int mode) {
         }
         return best;
     }
-    return wfd_gemm_pick_splits(M, N, K);
+    // small products: the bf16 pipe is not the limit, slab traffic is -- at most 8 splits
+    const int s = wfd_gemm_pick_splits(M, N, K);
+    return s > 8 ? 8 : s;
 }
 
 // 1 when the fused conv entry points run a (Bn*L, Cin, Cout) conv with the LDS-resident kernel (no K split needed: the

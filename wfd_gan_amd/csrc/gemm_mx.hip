@@ -89,6 +89,52 @@ __device__ __forceinline__ void mx_load(float4 (&r)[NLD], const float* __restric
     }
 }
 
+// Interior k-tiles (the whole tile inside the split's k-range) take a branch-free form: per-thread element offsets are
+// computed once before the k-loop with out-of-range rows / columns CLAMPED to valid ones -- what they load only feeds
+// output rows / columns that are never stored -- so a tile is NLD unconditional 16-byte loads at offset + constant.
+// (Leading dimensions are multiples of 4 floats, so a 16-byte load that starts inside a row stays inside its
+// allocation; offsets are 32-bit element counts -- the entry points reject operands of 2^31 elements or more.)  The implicit-GEMM operand additionally zeroes taps that fall outside the sample.
+template <int T, int KT, bool KC, bool IM2COL, int NLD>
+__device__ __forceinline__ void mx_offsets(int (&off)[NLD], int (&lpos)[NLD], int ld, int row0, int nrows, int kbeg, int tid,
+                                           int convL, int convCin, int convPad) {
+    constexpr int QK = KT / 4, QM = T / 4;
+#pragma unroll
+    for (int j = 0; j < NLD; ++j) {
+        if constexpr (KC) {
+            const int gr = min(row0 + tid / QK + (XT / QK) * j, nrows - 1), gk = kbeg + 4 * (tid % QK);
+            if constexpr (IM2COL) {
+                off[j] = gr * convCin + gk - convPad * convCin;
+                lpos[j] = gr % convL - convPad;
+            } else {
+                off[j] = gr * ld + gk;
+                lpos[j] = 0;
+            }
+        } else {
+            int gc = row0 + 4 * (tid % QM);
+            if (gc >= nrows) gc = 0;
+            off[j] = (kbeg + tid / QM + (XT / QM) * j) * ld + gc;
+            lpos[j] = 0;
+        }
+    }
+}
+
+template <int T, int KT, bool KC, bool IM2COL, int NLD>
+__device__ __forceinline__ void mx_load_fast(float4 (&r)[NLD], const float* __restrict__ G, const int (&off)[NLD],
+                                             const int (&lpos)[NLD], int step, int k0, int tid, int convL, int convCin) {
+    if constexpr (IM2COL) {
+        const int t = (k0 + 4 * (tid % (KT / 4))) / convCin;
+#pragma unroll
+        for (int j = 0; j < NLD; ++j) {
+            const bool ok = (unsigned)(lpos[j] + t) < (unsigned)convL;
+            const float4 v = *reinterpret_cast<const float4*>(G + (ok ? off[j] + step : 0));
+            r[j] = ok ? v : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+    } else {
+#pragma unroll
+        for (int j = 0; j < NLD; ++j) r[j] = *reinterpret_cast<const float4*>(G + off[j] + step);
+    }
+}
+
 // ---- registers -> bf16 (hi [, lo]) -> LDS --------------------------------------------------------------------------
 template <int T, int KT, bool KC, int TERMS, int NLD>
 __device__ __forceinline__ void mx_store(const float4 (&r)[NLD], __bf16* __restrict__ S, int tid) {
@@ -159,23 +205,31 @@ __global__ __launch_bounds__(XT) void gemm_mx_kernel(GemmArgs g, int kchunk, int
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
 
-    float4 ra[G_::NLD], rb[G_::NLD];
-    if (nk > 0) {
-        mx_load<T, KT, AKC, IM2COL>(ra, g.A, g.lda, m0, g.M, kbeg, kend, tid, g.convL, g.convCin, g.convPad);
-        mx_load<T, KT, BKC, false>(rb, g.B, g.ldb, n0, g.N, kbeg, kend, tid, 0, 0, 0);
-        mx_store<T, KT, AKC, TERMS>(ra, smem, tid);
-        mx_store<T, KT, BKC, TERMS>(rb, smem + TERMS * IMG_A, tid);
-    }
-    __syncthreads();
-    int cur = 0;
-    for (int kt = 0; kt < nk; ++kt) {
-        const bool more = kt + 1 < nk;
-        if (more) {
-            const int k0 = kbeg + (kt + 1) * KT;
+    // One register set, one tile ahead: the global loads of tile kt + 1 are issued before tile kt is multiplied out of
+    // LDS buffer kt & 1 and go to the other buffer at the end of the step.  (A second set with the loads two tiles ahead
+    // costs a workgroup per CU in registers: measured 530 -> 323 TF at M = 8192.)
+    float4 ra0[G_::NLD], rb0[G_::NLD];
+    int offa[G_::NLD], offb[G_::NLD];
+    int lpa[G_::NLD], lpb[G_::NLD];
+    mx_offsets<T, KT, AKC, IM2COL>(offa, lpa, g.lda, m0, g.M, kbeg, tid, g.convL, g.convCin, g.convPad);
+    mx_offsets<T, KT, BKC, false>(offb, lpb, g.ldb, n0, g.N, kbeg, tid, 0, 0, 0);
+    const int stepa = AKC ? KT : KT * g.lda, stepb = BKC ? KT : KT * g.ldb;
+    auto load_tile = [&](int kt, float4 (&ra)[G_::NLD], float4 (&rb)[G_::NLD]) {
+        const int k0 = kbeg + kt * KT;
+        if (k0 + KT <= kend) {          // wave-uniform: interior tile
+            mx_load_fast<T, KT, AKC, IM2COL>(ra, g.A, offa, lpa, kt * stepa, k0, tid, g.convL, g.convCin);
+            mx_load_fast<T, KT, BKC, false>(rb, g.B, offb, lpb, kt * stepb, k0, tid, 0, 0);
+        } else {                        // ragged last tile of the split
             mx_load<T, KT, AKC, IM2COL>(ra, g.A, g.lda, m0, g.M, k0, kend, tid, g.convL, g.convCin, g.convPad);
             mx_load<T, KT, BKC, false>(rb, g.B, g.ldb, n0, g.N, k0, kend, tid, 0, 0, 0);
         }
-        const __bf16* a_s = smem + cur * BUF;
+    };
+    auto store_tile = [&](int buf, const float4 (&ra)[G_::NLD], const float4 (&rb)[G_::NLD]) {
+        mx_store<T, KT, AKC, TERMS>(ra, smem + buf * BUF, tid);
+        mx_store<T, KT, BKC, TERMS>(rb, smem + buf * BUF + TERMS * IMG_A, tid);
+    };
+    auto compute = [&](int buf) {
+        const __bf16* a_s = smem + buf * BUF;
         const __bf16* b_s = a_s + TERMS * IMG_A;
 #pragma unroll
         for (int s = 0; s < KT / 16; ++s) {
@@ -200,12 +254,18 @@ __global__ __launch_bounds__(XT) void gemm_mx_kernel(GemmArgs g, int kchunk, int
                     acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[a], bh[b], acc[a][b], 0, 0, 0);
                 }
         }
-        if (more) {
-            mx_store<T, KT, AKC, TERMS>(ra, smem + (cur ^ 1) * BUF, tid);
-            mx_store<T, KT, BKC, TERMS>(rb, smem + (cur ^ 1) * BUF + TERMS * IMG_A, tid);
-        }
+    };
+    if (nk > 0) {
+        load_tile(0, ra0, rb0);
+        store_tile(0, ra0, rb0);
+    }
+    __syncthreads();
+    for (int kt = 0; kt < nk; ++kt) {
+        const bool more = kt + 1 < nk;
+        if (more) load_tile(kt + 1, ra0, rb0);
+        compute(kt & 1);
+        if (more) store_tile((kt + 1) & 1, ra0, rb0);
         __syncthreads();
-        cur ^= 1;
     }
 
     // C/D map of a 32x32 accumulator: col = lane & 31, row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)
