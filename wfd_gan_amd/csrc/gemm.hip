@@ -128,6 +128,57 @@ __device__ __forceinline__ void store_tile(const float (&r)[8], float* __restric
     }
 }
 
+// Interior k-tiles (whole tile inside the split's k-range) of 16-byte-aligned operands take a branch-free form: the
+// per-thread element offsets are computed once before the k-loop with out-of-range rows / columns CLAMPED to valid
+// ones (what they load only feeds output rows / columns that are never stored), so a tile is two unconditional
+// 16-byte loads at offset + constant.  Leading dimensions are multiples of 4 floats here, so a 16-byte load that
+// starts inside a row stays inside its allocation.  The implicit-GEMM operand also zeroes taps outside the sample.
+template <bool KC, bool IM2COL>
+__device__ __forceinline__ void tile_offsets(int (&off)[2], int (&lpos)[2], int ld, int row0, int nrows, int kbeg, int tid,
+                                             int convL, int convCin, int convPad) {
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        lpos[j] = 0;
+        if constexpr (KC) {
+            const int gr = min(row0 + (tid >> 3) + 32 * j, nrows - 1), gk = kbeg + 4 * (tid & 7);
+            if constexpr (IM2COL) {
+                off[j] = gr * convCin + gk - convPad * convCin;
+                lpos[j] = gr % convL - convPad;
+            } else {
+                off[j] = gr * ld + gk;
+            }
+        } else {
+            int gc = row0 + 4 * (tid & 15);
+            if (gc >= nrows) gc = 0;
+            if constexpr (IM2COL) {       // conv weight gradient: rows are (sample, position), columns (tap, cin)
+                off[j] = (kbeg + (tid >> 4) + 16 * j) * convCin + gc - convPad * convCin;
+                lpos[j] = gc / convCin - convPad;
+            } else {
+                off[j] = (kbeg + (tid >> 4) + 16 * j) * ld + gc;
+            }
+        }
+    }
+}
+
+template <bool KC, bool IM2COL>
+__device__ __forceinline__ void load_tile_fast(float (&r)[8], const float* __restrict__ G, const int (&off)[2],
+                                               const int (&lpos)[2], int step, int k0, int tid, int convL, int convCin) {
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        float4 v;
+        if constexpr (IM2COL) {
+            bool ok;
+            if constexpr (KC) ok = (unsigned)(lpos[j] + (k0 + 4 * (tid & 7)) / convCin) < (unsigned)convL;
+            else ok = (unsigned)((k0 + (tid >> 4) + 16 * j) % convL + lpos[j]) < (unsigned)convL;
+            v = *reinterpret_cast<const float4*>(G + (ok ? off[j] + step : 0));
+            if (!ok) v = make_float4(0.f, 0.f, 0.f, 0.f);
+        } else {
+            v = *reinterpret_cast<const float4*>(G + off[j] + step);
+        }
+        r[4 * j + 0] = v.x; r[4 * j + 1] = v.y; r[4 * j + 2] = v.z; r[4 * j + 3] = v.w;
+    }
+}
+
 // fragment of MFMA steps s = 0..3 of k-group kk for the 32-row block starting at row0 (i = lane & 31, h = lane >> 5)
 template <bool KC>
 __device__ __forceinline__ f32x4 read_frag(const float* __restrict__ S, int row0, int kk, int i, int h) {
@@ -162,9 +213,29 @@ __global__ __launch_bounds__(NTHREADS) void gemm_f32_kernel(GemmArgs g) {
     for (int r = 0; r < 16; ++r) acc[r] = 0.f;
 
     float ra[8], rb[8];
+    constexpr bool FAST = (VA == 4 && VB == 4);
+    int offa[2], offb[2], lpa[2], lpb[2];
+    int stepa = 0, stepb = 0;
+    if constexpr (FAST) {
+        tile_offsets<AKC, IM2COL && AKC>(offa, lpa, g.lda, m0, g.M, kbeg, tid, g.convL, g.convCin, g.convPad);
+        tile_offsets<BKC, IM2COL && !AKC>(offb, lpb, g.ldb, n0, g.N, kbeg, tid, g.convL, g.convCin, g.convPad);
+        stepa = AKC ? BK : BK * g.lda;
+        stepb = BKC ? BK : BK * ((IM2COL && !AKC) ? g.convCin : g.ldb);
+    }
+    auto load_both = [&](int kt) {
+        const int k0 = kbeg + kt * BK;
+        bool fast = false;
+        if constexpr (FAST) fast = k0 + BK <= kend;        // wave-uniform: interior tile
+        if (fast) {
+            load_tile_fast<AKC, IM2COL && AKC>(ra, g.A, offa, lpa, kt * stepa, k0, tid, g.convL, g.convCin);
+            load_tile_fast<BKC, IM2COL && !AKC>(rb, g.B, offb, lpb, kt * stepb, k0, tid, g.convL, g.convCin);
+        } else {
+            load_tile<AKC, VA, IM2COL && AKC>(ra, g.A, g.lda, m0, g.M, k0, kend, tid, g.convL, g.convCin, g.convPad);
+            load_tile<BKC, VB, IM2COL && !AKC>(rb, g.B, g.ldb, n0, g.N, k0, kend, tid, g.convL, g.convCin, g.convPad);
+        }
+    };
     if (nk > 0) {
-        load_tile<AKC, VA, IM2COL && AKC>(ra, g.A, g.lda, m0, g.M, kbeg, kend, tid, g.convL, g.convCin, g.convPad);
-        load_tile<BKC, VB, IM2COL && !AKC>(rb, g.B, g.ldb, n0, g.N, kbeg, kend, tid, g.convL, g.convCin, g.convPad);
+        load_both(0);
         store_tile<AKC, VA>(ra, lds, tid);
         store_tile<BKC, VB>(rb, lds + TILE_F, tid);
     }
@@ -172,11 +243,7 @@ __global__ __launch_bounds__(NTHREADS) void gemm_f32_kernel(GemmArgs g) {
     int cur = 0;
     for (int kt = 0; kt < nk; ++kt) {
         const bool more = kt + 1 < nk;
-        if (more) {
-            const int k0 = kbeg + (kt + 1) * BK;
-            load_tile<AKC, VA, IM2COL && AKC>(ra, g.A, g.lda, m0, g.M, k0, kend, tid, g.convL, g.convCin, g.convPad);
-            load_tile<BKC, VB, IM2COL && !AKC>(rb, g.B, g.ldb, n0, g.N, k0, kend, tid, g.convL, g.convCin, g.convPad);
-        }
+        if (more) load_both(kt + 1);
         const float* a_s = lds + cur * 2 * TILE_F;
         const float* b_s = a_s + TILE_F;
         if constexpr (!NARROW) {
@@ -350,11 +417,28 @@ __global__ __launch_bounds__(NTHREADS) void gemm_f32_nt128_kernel(GemmArgs g, in
             for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
 
     float ra[2][8], rb[2][8];
+    int offa[2][2], offb[2][2], lpu[2];
 #pragma unroll
     for (int q = 0; q < 2; ++q) {
-        load_tile<true, 4, false>(ra[q], g.A, g.lda, m0 + 64 * q, g.M, 0, g.K, tid, 0, 0, 0);
-        load_tile<true, 4, false>(rb[q], g.B, g.ldb, n0 + 64 * q, g.N, 0, g.K, tid, 0, 0, 0);
+        tile_offsets<true, false>(offa[q], lpu, g.lda, m0 + 64 * q, g.M, 0, tid, 0, 0, 0);
+        tile_offsets<true, false>(offb[q], lpu, g.ldb, n0 + 64 * q, g.N, 0, tid, 0, 0, 0);
     }
+    auto load_all = [&](int k0) {
+        if (k0 + BK <= g.K) {           // interior tile: branch-free loads at clamped offsets
+#pragma unroll
+            for (int q = 0; q < 2; ++q) {
+                load_tile_fast<true, false>(ra[q], g.A, offa[q], lpu, k0, k0, tid, 0, 0);
+                load_tile_fast<true, false>(rb[q], g.B, offb[q], lpu, k0, k0, tid, 0, 0);
+            }
+        } else {
+#pragma unroll
+            for (int q = 0; q < 2; ++q) {
+                load_tile<true, 4, false>(ra[q], g.A, g.lda, m0 + 64 * q, g.M, k0, g.K, tid, 0, 0, 0);
+                load_tile<true, 4, false>(rb[q], g.B, g.ldb, n0 + 64 * q, g.N, k0, g.K, tid, 0, 0, 0);
+            }
+        }
+    };
+    load_all(0);
 #pragma unroll
     for (int q = 0; q < 2; ++q) {
         store_tile<true, 4>(ra[q], smem + 64 * q * LDK, tid);
@@ -364,14 +448,7 @@ __global__ __launch_bounds__(NTHREADS) void gemm_f32_nt128_kernel(GemmArgs g, in
     int cur = 0;
     for (int kt = 0; kt < nk; ++kt) {
         const bool more = kt + 1 < nk;
-        if (more) {
-            const int k0 = (kt + 1) * BK;
-#pragma unroll
-            for (int q = 0; q < 2; ++q) {
-                load_tile<true, 4, false>(ra[q], g.A, g.lda, m0 + 64 * q, g.M, k0, g.K, tid, 0, 0, 0);
-                load_tile<true, 4, false>(rb[q], g.B, g.ldb, n0 + 64 * q, g.N, k0, g.K, tid, 0, 0, 0);
-            }
-        }
+        if (more) load_all((kt + 1) * BK);
         const float* a_s = smem + cur * 2 * T128_F;
         const float* b_s = a_s + T128_F;
 #pragma unroll
@@ -433,7 +510,10 @@ int launch_nt128(const GemmArgs& g, hipStream_t st) {
 
 // the tall-tile form pays when its tiles alone give every CU work (no K split needed)
 inline bool use_nt128(int M, int N, int K, bool va4, bool vb4) {
-    return va4 && vb4 && M >= 1024 && K >= 64 && (long)cdiv(M, T128) * cdiv(N, T128) >= 192;
+    if (!(va4 && vb4 && M >= 1024 && K >= 64)) return false;
+    const long tiles = (long)cdiv(M, T128) * cdiv(N, T128);
+    // two workgroups fit a CU: skip grids whose last wave of 512 would run mostly empty (N = 1401: 704 tiles)
+    return tiles >= 192 && 5 * tiles >= 4 * 512L * cdiv(tiles, 512);
 }
 
 template <bool AKC, bool BKC, bool IM2COL>
@@ -447,6 +527,13 @@ int launch_gemm(const GemmArgs& g, int splits, bool va4, bool vb4, hipStream_t s
 }
 
 inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
+
+// the kernels index operands with 32-bit element offsets
+inline bool fits31(long rows, long ld) { return rows * ld < (1L << 31); }
+inline bool operands_fit(int layout, int M, int N, int K, int lda, int ldb) {
+    const long ra = layout == 2 ? K : M, rb = layout == 0 ? N : K;
+    return fits31(ra, lda) && fits31(rb, ldb);
+}
 
 // operand mode of the contraction entry points: 0 = f32-input MFMA (exact f32 products, the parity path),
 // 1 = bf16 operands, 2 = split-bf16 x3 (gemm_mx.hip).  Process-wide; read when a launch is issued (or captured).
@@ -518,6 +605,7 @@ int wfd_gemm_f32(int layout, const float* A, int lda, const float* B, int ldb, f
                  int M, int N, int K, int splits, void* stream) {
     if (!A || !B || !P || M <= 0 || N <= 0 || K <= 0 || splits < 1 || ldp < N) return WFD_ERR_ARG;
     if (splits > 1 && slab_stride < (long)M * ldp) return WFD_ERR_ARG;
+    if (!operands_fit(layout, M, N, K, lda, ldb)) return WFD_ERR_ARG;
     GemmArgs g{};
     g.A = A; g.B = B; g.P = P; g.M = M; g.N = N; g.K = K; g.lda = lda; g.ldb = ldb; g.ldp = ldp;
     g.slab_stride = slab_stride;
@@ -547,7 +635,7 @@ int wfd_gemm_f32(int layout, const float* A, int lda, const float* B, int ldb, f
 int wfd_conv8_gemm_f32(const float* X, int Bn, int L, int Cin, int pad, const float* Wp, int Cout, float* P, int ldp,
                        long slab_stride, int splits, void* stream) {
     if (!X || !Wp || !P || Bn <= 0 || L <= 0 || Cin <= 0 || (Cin & 3) || Cout <= 0 || ldp < Cout) return WFD_ERR_ARG;
-    if (!aligned16(X) || !aligned16(Wp)) return WFD_ERR_ARG;
+    if (!aligned16(X) || !aligned16(Wp) || !fits31((long)Bn * L, Cin)) return WFD_ERR_ARG;
     GemmArgs g{};
     g.A = X; g.B = Wp; g.P = P; g.M = Bn * L; g.N = Cout; g.K = 8 * Cin; g.lda = Cin; g.ldb = 8 * Cin; g.ldp = ldp;
     g.slab_stride = slab_stride;
@@ -568,6 +656,7 @@ int wfd_gemm_f32_fused(int layout, const float* A, int lda, const float* B, int 
                        int dmode, void* stream) {
     if (!A || !B || !out || M <= 0 || N <= 0 || K <= 0 || ldo < N || epi < 1 || epi > 2) return WFD_ERR_ARG;
     if (epi == 2 && dmode && !D) return WFD_ERR_ARG;
+    if (!operands_fit(layout, M, N, K, lda, ldb)) return WFD_ERR_ARG;
     GemmArgs g{};
     g.A = A; g.B = B; g.P = out; g.M = M; g.N = N; g.K = K; g.lda = lda; g.ldb = ldb; g.ldp = ldo;
     g.ktiles_per_split = cdiv(K, BK);
@@ -595,6 +684,7 @@ int wfd_conv8_gemm_f32_fused(const float* X, int Bn, int L, int Cin, int pad, co
                              int dmode, void* stream) {
     if (!X || !Wp || !out || Bn <= 0 || L <= 0 || Cin <= 0 || (Cin & 3) || Cout <= 0 || ldo < Cout) return WFD_ERR_ARG;
     if (!aligned16(X) || !aligned16(Wp) || epi < 1 || epi > 2 || (epi == 2 && dmode && !D)) return WFD_ERR_ARG;
+    if (!fits31((long)Bn * L, Cin)) return WFD_ERR_ARG;
     GemmArgs g{};
     g.A = X; g.B = Wp; g.P = out; g.M = Bn * L; g.N = Cout; g.K = 8 * Cin; g.lda = Cin; g.ldb = 8 * Cin; g.ldp = ldo;
     g.ktiles_per_split = cdiv(g.K, BK);
@@ -615,6 +705,7 @@ int wfd_conv8_wgrad_f32(const float* dY, const float* X, int Bn, int L, int Cin,
     if (!dY || !X || !P || Bn <= 0 || L <= 0 || Cin <= 0 || (Cin & 3) || Cout <= 0 || (Cout & 3) || splits < 1)
         return WFD_ERR_ARG;
     if (!aligned16(dY) || !aligned16(X) || ldp < 8 * Cin) return WFD_ERR_ARG;
+    if (!fits31((long)Bn * L, Cin) || !fits31((long)Bn * L, Cout)) return WFD_ERR_ARG;
     if (splits > 1 && slab_stride < (long)Cout * ldp) return WFD_ERR_ARG;
     GemmArgs g{};
     g.A = dY; g.B = X; g.P = P; g.M = Cout; g.N = 8 * Cin; g.K = Bn * L; g.lda = Cout; g.ldb = 8 * Cin; g.ldp = ldp;
