@@ -57,6 +57,9 @@ def parse_args(argv=None):
     # additive
     p.add_argument("--penalty", choices=["div", "gp"], default="div",
                    help="div = W-div (what the reference runs); gp = interpolated WGAN-GP (utils.py:64-84)")
+    p.add_argument("--operands", choices=["f32", "bf16x3", "bf16"], default="f32",
+                   help="contraction operands: f32 = f32-input MFMA, exact f32 products (default, the parity path); "
+                        "bf16x3 = split-bf16 on the bf16 matrix pipe (products ~1e-5 relative); bf16 = bf16 operands")
     p.add_argument("--seed", type=int, default=None, help="seed for init / shuffling / device RNG")
     p.add_argument("--no_graph", action="store_true", help="launch kernels eagerly instead of HIP-graph replay")
     p.add_argument("--no_group", action="store_true",
@@ -159,7 +162,7 @@ def main(argv=None):
         t = torch.tensor([seed], dtype=torch.int64, device=device)
         parallel.broadcast_state_([t])
         seed = int(t.item())
-    dp = dict(world_size=world, rank=rank, sync_bn=exact)
+    dp = dict(world_size=world, rank=rank, sync_bn=exact, operands=args.operands)
     rng_seed = seed + 1000003 * rank
     eng = TrainEngine(seq_len, class_dim, args.latent_dim, B, scaler.data_min_[0], scaler.data_max_[0],
                       generator.state_dict(), discriminator.state_dict(), f_model.state_dict(), lr=args.lr,
