@@ -99,3 +99,77 @@ def trainer_worker(rank, world, port, argv, q):
     except BaseException as e:  # noqa: BLE001
         import traceback
         q.put((rank, None, f"rank {rank} raised: {e!r}\n{traceback.format_exc()}"))
+
+
+def weak_worker(rank, world, port, name, q):
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK="0", MASTER_ADDR="127.0.0.1",
+                      MASTER_PORT=str(port))
+    try:
+        q.put((rank, _run_weak(rank, world, name)))
+    except Exception as e:  # noqa: BLE001
+        import traceback
+        q.put((rank, [f"rank {rank} raised: {e!r}\n{traceback.format_exc()}"]))
+
+
+def _run_weak(rank, world, name):
+    """Weak (DDP-semantics) mode: every rank steps on its OWN batch (rank r feeds the fixture's iteration-r inputs); the
+    bucketed all-reduce must leave the SUM of the ranks' local gradients in every element of both flat gradient buffers
+    (an element outside every bucket would keep its local value and differ between the ranks), and the replicas must stay
+    bit-identical."""
+    import torch.distributed as dist
+    from tests.util import load_iter_fixture, rebuild_state, unpack_masks
+    from wfd_gan_amd import parallel
+    from wfd_gan_amd.engine import TrainEngine
+    parallel.init_from_env(backend="gloo")
+    torch.cuda.set_device(0)
+    fx, meta = load_iter_fixture(name)
+    B = meta["batch"]
+
+    def mk(w):
+        st = rebuild_state(meta, fx)
+        return TrainEngine(meta["seq_len"], meta["class_dim"], meta["latent_dim"], B, meta["scaler_min"], meta["scaler_max"],
+                           {k: v.detach() for k, v in st.G.items()}, {k: v.detach() for k, v in st.D.items()}, st.DF,
+                           lr=meta["lr"], alpha=meta["alpha"], n_critic=meta["n_critic"], world_size=w, rank=rank if w > 1 else 0)
+    eng, loc = mk(world), mk(1)
+    assert eng.dp and not loc.dp and abs(eng.gscale - 1.0 / world) < 1e-12
+    # the three buckets tile each flat gradient buffer exactly
+    for which, fp in (("D", eng.Dp), ("G", eng.Gp)):
+        cover = sorted(eng.grad_buckets(which))
+        assert cover[0][0] == 0 and cover[-1][1] == fp.numel and all(a[1] == b[0] for a, b in zip(cover, cover[1:]))
+    p = f"it{rank % meta['n_iter']}_"
+    mr, mf, mg = (unpack_masks(fx, p + k, B) for k in ("mreal", "mfake", "mg"))
+    if mg is None:
+        mg = unpack_masks(fx, "it0_mg", B)
+    bad = []
+
+    def gathered(t):
+        h = t.detach().cpu()
+        parts = [torch.empty_like(h) for _ in range(world)]
+        dist.all_gather(parts, h)
+        return parts
+    for e in (eng, loc):
+        e.set_batch(torch.from_numpy(fx[p + "traces"]), torch.from_numpy(fx[p + "labels"]), torch.from_numpy(fx[p + "z"]))
+        e.set_masks([torch.cat([x, y]) for x, y in zip(mr, mf)], mg)
+    loc.d_step()
+    eng.d_step()
+    torch.cuda.synchronize()
+    want = torch.stack(gathered(loc.Dp.grad)).double().sum(0)
+    got = gathered(eng.Dp.grad)
+    if not all(torch.equal(got[0], t) for t in got[1:]):
+        bad.append(f"rank {rank}: critic gradient buffers differ between ranks after the all-reduce")
+    err = float((got[0].double() - want).abs().max()) / float(want.abs().max())
+    if err > 1e-6:
+        bad.append(f"rank {rank}: summed critic gradient off by {err:.2e}")
+    eng.g_step()
+    eng.d_step()
+    torch.cuda.synchronize()
+    for nme, t in (("G grad", eng.Gp.grad), ("D grad", eng.Dp.grad), ("G params", eng.Gp.flat), ("D params", eng.Dp.flat),
+                   ("G sq", eng.Gp.sq), ("D sq", eng.Dp.sq)):
+        parts = gathered(t)
+        if not all(torch.equal(parts[0], x) for x in parts[1:]):
+            bad.append(f"rank {rank}: {nme} differs between ranks (max |d| = {float((parts[0] - parts[-1]).abs().max()):.3e})")
+    if float(eng.Gp.grad.abs().max()) == 0.0:
+        bad.append("generator gradient is zero")
+    dist.barrier()
+    dist.destroy_process_group()
+    return bad

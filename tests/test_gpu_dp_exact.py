@@ -8,7 +8,7 @@ import pytest
 import torch
 import torch.multiprocessing as mp
 
-from tests.dp_exact_worker import trainer_worker, worker
+from tests.dp_exact_worker import trainer_worker, weak_worker, worker
 
 pytestmark = pytest.mark.gpu
 
@@ -27,6 +27,24 @@ def test_exact_dp_equals_reference_update(name, world):
     q = ctx.Queue()
     port = _free_port()
     procs = [ctx.Process(target=worker, args=(r, world, port, name, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    out = [q.get(timeout=280) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+    bad = [m for _, msgs in out for m in msgs]
+    assert not bad, "\n".join(bad)
+    assert all(p.exitcode == 0 for p in procs)
+
+
+@pytest.mark.parametrize("name,world", [("cfg1", 2), ("cfg2", 3)])
+def test_weak_dp_buckets_sum_every_gradient(name, world):
+    """Weak mode (per-rank batches, bucketed asynchronous all-reduce): the flat gradient buffers hold the sum of the ranks'
+    local gradients everywhere and the replicas stay bit-identical (ranks share cuda:0, gloo)."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=weak_worker, args=(r, world, port, name, q)) for r in range(world)]
     for p in procs:
         p.start()
     out = [q.get(timeout=280) for _ in procs]

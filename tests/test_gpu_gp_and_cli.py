@@ -144,7 +144,7 @@ def test_data_parallel_staging_world1_nccl():
         for e in (e1, e2):
             e.attach_dataset(torch.from_numpy(Xs), torch.from_numpy(y), shuffle_seed=5)
             e.capture_graphs()
-        assert len(e2.graph_d) == 5 and len(e1.graph_d) == 1      # stage, start, stage, start+finish, stage
+        assert len(e2.graph_d) == 7 and len(e1.graph_d) == 1      # stage, start, stage, start, stage, start+finish, stage
         for i in range(7):
             e1.iteration(i)
             e2.iteration(i)

@@ -460,6 +460,15 @@ class TrainEngine:
                              b["V"], b["DL3"][:M], b["DL3"][M:], b["DV"])
         g = self._critic_chain(p, M, b["DL3"][:M], b["DL2"][:M], b["DL2"][M:], b["DL1"][:M], b["DL1"][M:], b["D2"],
                                b["D1"], b["DV"])
+        bias_segs = [
+            (b["DL1"][M:], 2048, None, None, 0, None, M, 2048, D.g["model.0.bias"]),
+            (b["DL2"][M:], 1024, None, None, 0, None, M, 1024, D.g["model.3.bias"]),
+            (b["DL3"][M:], 512, None, None, 0, None, M, 512, D.g["model.6.bias"])]
+        if self.dp:
+            # data parallel: the bias gradients (column sums of dv o delta_i, final once the chain is) are produced here,
+            # ahead of the weight gradients, so that [W1, b1] and [W2, b2] can go out as whole buckets early
+            self._colsum_multi(p, "d_bias", bias_segs)
+            bias_segs = []
         mode = 0 if self.penalty == "div" else 1
         p.add(self.L.ep_penalty_row, g.ptr, g.ns, g.ss, g.ldp, M, S, mode, 1.0 / self.Bg, self.lambda_gp,
               ptr(b["PENFLAG"]), ptr(b["NSQ"]), ptr(b["PEN"]), ptr(b["XC"]), self.ldx)
@@ -471,12 +480,13 @@ class TrainEngine:
         with p.side():
             p.gemm(TN, b["DL1"], 2048, b["XC"], self.ldx, 2048, S + C, 2 * M, out=D.g["model.0.weight"],
                    ldp=D.ld["model.0.weight"])
-        self._grad_bucket_hook(p, "D", first=True)
+        self._grad_bucket_hook(p, "D", 0)
         s = p.gemm(NT, b["XC"], self.ldx, Dp["model.0.weight"], D.ld["model.0.weight"], M, 2048, S)
         p.mul(s, b["D1"], 2048, DM_MUL, None, None, b["T1H1"][:M], None, 2048)
         p.fork()
         with p.side():
             p.gemm(TN, b["DL2"], 1024, b["T1H1"], 2048, 1024, 2048, 2 * M, out=D.g["model.3.weight"], ldp=2048)
+        self._grad_bucket_hook(p, "D", 1)
         s = p.gemm(NT, b["T1H1"][:M], 2048, Dp["model.3.weight"], 2048, M, 1024, 2048)
         p.mul(s, b["D2"], 1024, DM_MUL, None, None, b["T2H2"][:M], None, 1024)
         p.fork()
@@ -484,10 +494,7 @@ class TrainEngine:
             p.gemm(TN, b["DL3"], 512, b["T2H2"], 1024, 512, 1024, 2 * M, out=D.g["model.6.weight"], ldp=1024)
         s = p.gemm(NT, b["T2H2"][:M], 1024, Dp["model.6.weight"], 1024, M, 512, 1024)
         p.mul(s, b["D3"], 512, DM_MUL, None, None, b["T3"], None, 512)
-        self._colsum_multi(p, "d_small", [
-            (b["DL1"][M:], 2048, None, None, 0, None, M, 2048, D.g["model.0.bias"]),
-            (b["DL2"][M:], 1024, None, None, 0, None, M, 1024, D.g["model.3.bias"]),
-            (b["DL3"][M:], 512, None, None, 0, None, M, 512, D.g["model.6.bias"]),
+        self._colsum_multi(p, "d_small", bias_segs + [
             (b["T3"], 512, None, b["H3"], 512, b["DV"], M, 512, D.g["model.9.weight"]),
             (b["DV"], 1, None, None, 0, None, M, 1, D.g["model.9.bias"]),
             # loss scalars of :215-227 as weighted column sums of the per-row critic scores / penalties:
@@ -515,30 +522,38 @@ class TrainEngine:
         self.buf["desc_" + name] = desc
         p.add(self.L.colsum_multi, ptr(desc), len(rows), blk)
 
-    def _grad_bucket_hook(self, p: Plan, which: str, first: bool):
-        """Data parallel: all-reduce the flat gradient buffer in two buckets.  The first bucket is the largest weight
-        gradient (critic W1: 12.3 MB of 22.8; generator W8: 11.5 MB of 23.2), which the backward produces first; its
-        all-reduce runs while the remaining backward GEMMs execute.  The second bucket goes out when everything is
-        final, and the optimizer waits for both."""
+    def _grad_bucket_hook(self, p: Plan, which: str, stage: int):
+        """Data parallel: all-reduce the flat gradient buffer in three buckets, each launched (asynchronously, on the
+        collective's stream) as soon as its slice is final, so that only the last, small one is exposed:
+          critic     0: [W1, b1] (12.3 MB, right after the first weight-gradient GEMM)   1: [W2, b2] (8.4 MB)
+                     2: [W3, b3, w4, b4] (2.1 MB, end of the step)
+          generator  0: [W8, b8] (11.5 MB, produced first by the backward)   1: [W5, b5, BN6] (8.4 MB)
+                     2: [W0, b0, W2, b2, BN3] (3.3 MB, end of the step)
+        The optimizer waits for all three (stage 2 also finishes)."""
         if not self.dp:
             return
         if self._gsync is None:
             from .parallel import GradSync
             self._gsync = GradSync(self.pg)
+        lo, hi = self.grad_buckets(which)[stage]
         fp = self.Dp if which == "D" else self.Gp
-        key = "model.0.weight" if which == "D" else "model.8.weight"
-        lo = fp.offsets[key]
-        hi = lo + fp.p[key].shape[0] * fp.ld[key] if which == "D" else fp.numel
-        big = fp.grad[lo:hi]
-        rest = fp.grad[hi:] if which == "D" else fp.grad[:lo]
+        bucket = fp.grad[lo:hi]
         gs = self._gsync
-        if first:
-            p.host(lambda: gs.start(big))
+        if stage < 2:
+            p.host(lambda: gs.start(bucket))
         else:
-            p.host(lambda: (gs.start(rest), gs.finish()))
+            p.host(lambda: (gs.start(bucket), gs.finish()))
+
+    def grad_buckets(self, which: str):
+        """[(begin, end)] x 3 element ranges of the flat gradient buffer, in the order the backward completes them."""
+        if which == "D":
+            o, n = self.Dp.offsets, self.Dp.numel
+            return [(0, o["model.3.weight"]), (o["model.3.weight"], o["model.6.weight"]), (o["model.6.weight"], n)]
+        o, n = self.Gp.offsets, self.Gp.numel
+        return [(o["model.8.weight"], n), (o["model.5.weight"], o["model.8.weight"]), (0, o["model.5.weight"])]
 
     def _grad_sync_hook(self, p: Plan, which: str):
-        self._grad_bucket_hook(p, which, first=False)
+        self._grad_bucket_hook(p, which, 2)
 
     def _observer(self, p: Plan):
         """DF forward on fake[:, 1:], masked CE, and the input gradient dDF (src/mlp_df_wgan_train.py:251-263,273)."""
@@ -615,7 +630,7 @@ class TrainEngine:
         p.fork()
         with p.side():
             p.gemm(TN, b["GDZ4"], self.lds4, b["GH3"], 2048, S, 2048, B, out=G.g["model.8.weight"], ldp=2048)
-        self._grad_bucket_hook(p, "G", first=True)
+        self._grad_bucket_hook(p, "G", 0)
         prev_dz, kdz, wkey = b["GDZ4"], S, "model.8.weight"
         lddz = self.lds4
         for i, lin, bn, n, hin, kin in ((3, "model.5", "model.6", 2048, b["GH2"], 1024),
@@ -625,6 +640,8 @@ class TrainEngine:
             p.fork()
             with p.side():
                 p.gemm(TN, b[f"GDZ{i}"], n, hin, kin, n, kin, B, out=G.g[f"{lin}.weight"], ldp=kin)
+            if i == 3:
+                self._grad_bucket_hook(p, "G", 1)
             prev_dz, kdz, wkey, lddz = b[f"GDZ{i}"], n, f"{lin}.weight", n
         s = p.gemm(NN, prev_dz, 1024, Gp["model.2.weight"], 512, B, 512, 1024)
         p.mul(s, b["GH1"], 512, DM_RELU, None, None, b["GDZ1"], None, 512)
