@@ -239,6 +239,15 @@ int wfd_minmax_transform_f64(const double* X, long N, int S, const double* scale
 /* --clip: my_clip over every row, src/mlp_df_wgan_train.py:82-91,122 (float64, in place) */
 int wfd_clip_bursts(double* X, long N, int S, double max_len, double max_out, double max_in, void* stream);
 
+/* Burst extraction, the on-disk -> npz step in front of the trainer: extract.get_burst + extract.extract, src/extract.py:58-123,
+ * for `ntraces` packet traces stored ragged (trace i = entries off[i] .. off[i+1] of `times` / `sizes`, float64, every
+ * trace non-empty).  feat[i][0..S) = [number of bursts, |burst size sums| (divided by cell_norm when > 0: --norm), 0 ...];
+ * bsum / btime (as long as times) receive trace i's signed burst sums / burst start times at off[i] + r; meta[i] =
+ * {first kept packet, end of the kept range, number of bursts} (the host evaluates the reference's asserts :106-107
+ * from them). */
+int wfd_extract_bursts(const double* times, const double* sizes, const long long* off, int ntraces, int S, double cell_norm,
+                       double* feat, double* bsum, double* btime, int* meta, void* stream);
+
 /* sampler epilogue: MinMaxScaler.inverse_transform (float64 min_/scale_, fp32 data) + np.trim_zeros + np.round
  * (half-even) + astype(int) + 0 -> 1, src/generate.py:59-63.  out rows are zero-padded; len_out = lengths. */
 int wfd_sample_post(const float* Y, int ldy, int M, int S, const double* min_, const double* scale_, int* out, int ldo,

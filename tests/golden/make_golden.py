@@ -515,12 +515,12 @@ def make_df_train_case(ref_model, name, length, class_dim, batch, n_steps, seed)
 
 # ------------------------------------------------------------------------------------------------
 def make_cli_fixture():
-    """The command-line contracts of the three scripts on the path, read from the reference's own argparse calls
+    """The command-line contracts of the four scripts on the path, read from the reference's own argparse calls
     (ast of the source files; nothing is executed): flag names, dest-relevant options, types, defaults, required,
     action.  tests/test_cpu_abi.py compares the build's parsers against it."""
     import ast
     out = {}
-    for script in ("mlp_df_wgan_train.py", "generate.py", "train_df.py"):
+    for script in ("mlp_df_wgan_train.py", "generate.py", "train_df.py", "extract.py"):
         tree = ast.parse(open(os.path.join(REF_SRC, script)).read())
         args = []
         for node in ast.walk(tree):

@@ -88,17 +88,18 @@ def test_shard_rows_partitions():
 
 
 def test_cli_contract_matches_reference_argparse():
-    """tests/golden/cli_contract.json holds the argparse calls of the reference's three scripts on the path (read from
+    """tests/golden/cli_contract.json holds the argparse calls of the reference's four scripts on the path (read from
     their source by make_golden.py): every flag must be accepted by the build's parser under every alias, with the
     same type and the same default.  (generate.py's --train / --test are accepted but not required here: the bulk
     sampler reads the scaler from the model directory.)"""
     import json
-    from wfd_gan_amd import generate, mlp_df_wgan_train, train_df
+    from wfd_gan_amd import extract, generate, mlp_df_wgan_train, train_df
     contract = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "cli_contract.json")))
     mods = {"mlp_df_wgan_train.py": (mlp_df_wgan_train, ["-d", "X.npz", "--f_model", "df.ckpt"]),
             "generate.py": (generate, ["-m", "model_dir"]),
-            "train_df.py": (train_df, ["X.npz"])}
-    sample = {"int": ("3", 3), "float": ("0.5", 0.5), "str": ("abc", "abc"), None: ("abc", "abc")}
+            "train_df.py": (train_df, ["X.npz"]),
+            "extract.py": (extract, ["--dir", "traces"])}
+    sample = {"int": ("3", 3), "float": ("0.5", 0.5), "str": ("abc", "abc"), None: ("abc", "abc"), "bool": ("1", True)}
     for script, args in contract.items():
         mod, base = mods[script]
         ns0 = vars(mod.parse_args(base))

@@ -328,6 +328,76 @@ __global__ void minmax_transform_kernel(const double* __restrict__ X, long total
     }
 }
 
+// ---- burst extraction (src/extract.py:58-122) -------------------------------------------------------------------
+// One workgroup per packet trace (ragged: packets off[i] .. off[i+1] of the concatenated time / size arrays, float64).
+// Long-gap truncation (first / last inter-packet gap > 10 s), skip of the leading incoming packets, then the trace is
+// cut into runs of equal-sign packets: a run's thread (the one at its first packet) adds the sizes left to right, as
+// the reference's loop does, so the sums are bit-identical for any data.  Run indices come from a ballot / prefix
+// count per 256-packet block.
+__device__ __forceinline__ int sgn_f64(double x) { return (x > 0.0) - (x < 0.0); }
+
+__global__ __launch_bounds__(256) void extract_bursts_kernel(const double* __restrict__ T, const double* __restrict__ Sz,
+                                                             const long long* __restrict__ off, int S, double cell,
+                                                             double* __restrict__ feat, double* __restrict__ bsum,
+                                                             double* __restrict__ btime, int* __restrict__ meta) {
+    __shared__ int s_first, s_last, s_p0, s_wave[4];
+    const int i = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const long long o = off[i];
+    const int n = (int)(off[i + 1] - o);
+    const double* t = T + o;
+    const double* s = Sz + o;
+    if (tid == 0) { s_first = 0x7fffffff; s_last = -1; s_p0 = 0x7fffffff; }
+    __syncthreads();
+    int lf = 0x7fffffff, ll = -1;
+    for (int j = tid; j + 1 < n; j += 256)
+        if (t[j + 1] - t[j] > 10.0) { lf = min(lf, j); ll = max(ll, j); }
+    if (ll >= 0) { atomicMin(&s_first, lf); atomicMax(&s_last, ll); }
+    __syncthreads();
+    int start = 0, end = n;
+    if (s_last >= 0) {
+        if (s_first < 50) start = s_first + 1;
+        if (s_last > 50) end = s_last + 1;
+    }
+    int lp = 0x7fffffff;
+    for (int j = start + tid; j < end; j += 256)
+        if (s[j] > 0.0) { lp = j; break; }
+    if (lp != 0x7fffffff) atomicMin(&s_p0, lp);
+    __syncthreads();
+    const int p0 = s_p0 == 0x7fffffff ? end - 1 : s_p0;
+    const double t0 = t[p0];
+    int base = 0;
+    for (int c = p0; c < end; c += 256) {
+        const int q = c + tid;
+        const bool in = q < end;
+        const int sq = in ? sgn_f64(s[q]) : 0;
+        const bool flag = in && (q == p0 || sq != sgn_f64(s[q - 1]));
+        const unsigned long long m = __ballot(flag);
+        if (lane == 0) s_wave[wave] = __popcll(m);
+        __syncthreads();
+        int before = __popcll(m & ((1ull << lane) - 1ull)), total = 0;
+#pragma unroll
+        for (int w = 0; w < 4; ++w) {
+            if (w < wave) before += s_wave[w];
+            total += s_wave[w];
+        }
+        if (flag) {
+            const int r = base + before;
+            double sum = s[q];
+            for (int k = q + 1; k < end && sgn_f64(s[k]) == sq; ++k) sum += s[k];
+            bsum[o + r] = sum;
+            btime[o + r] = t[q] - t0;
+            if (r + 1 < S) feat[(long)i * S + 1 + r] = cell > 0.0 ? fabs(sum) / cell : fabs(sum);
+        }
+        base += total;
+        __syncthreads();
+    }
+    if (tid == 0) {
+        feat[(long)i * S] = (double)base;
+        meta[3 * i] = p0; meta[3 * i + 1] = end; meta[3 * i + 2] = base;
+    }
+    for (int j = 1 + min(base, S - 1) + tid; j < S; j += 256) feat[(long)i * S + j] = 0.0;
+}
+
 }  // namespace
 
 extern "C" {
@@ -477,6 +547,16 @@ int wfd_minmax_transform_f64(const double* X, long N, int S, const double* scale
     if (blocks > 16384) blocks = 16384;
     hipLaunchKernelGGL(minmax_transform_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, X, total, S, scale,
                        min_, out);
+    WFD_CHECK_LAUNCH();
+    return WFD_OK;
+}
+
+int wfd_extract_bursts(const double* times, const double* sizes, const long long* off, int ntraces, int S, double cell_norm,
+                       double* feat, double* bsum, double* btime, int* meta, void* stream) {
+    if (!times || !sizes || !off || !feat || !bsum || !btime || !meta || ntraces <= 0 || S < 1 || cell_norm < 0.0)
+        return WFD_ERR_ARG;
+    hipLaunchKernelGGL(extract_bursts_kernel, dim3(ntraces), dim3(256), 0, (hipStream_t)stream, times, sizes, off, S, cell_norm,
+                       feat, bsum, btime, meta);
     WFD_CHECK_LAUNCH();
     return WFD_OK;
 }
