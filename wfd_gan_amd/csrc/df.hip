@@ -18,14 +18,15 @@ __global__ void conv1_fwd_kernel(const float* __restrict__ X, int ldx, int xoff,
         const int l = l0 + tid - 3;
         xs[tid] = (l >= 0 && l < L) ? X[(long)b * ldx + xoff + l] : 0.f;
     }
-    for (int i = tid; i < Cout * 8; i += blockDim.x) ws[i] = W[i];
+    // taps stored [t][co]: the lanes of a wave differ in co, so a tap is read from consecutive banks
+    for (int i = tid; i < Cout * 8; i += blockDim.x) ws[(i & 7) * Cout + (i >> 3)] = W[i];
     __syncthreads();
     for (int o = tid; o < 64 * Cout; o += blockDim.x) {
         const int li = o / Cout, co = o - li * Cout;
         if (l0 + li >= L) break;
         float a = 0.f;
 #pragma unroll
-        for (int t = 0; t < 8; ++t) a = __fmaf_rn(ws[co * 8 + t], xs[li + t], a);
+        for (int t = 0; t < 8; ++t) a = __fmaf_rn(ws[t * Cout + co], xs[li + t], a);
         a = __fmaf_rn(a, scale[co], shift[co]);
         if (act == 1) a = fmaxf(a, 0.f);
         else if (act == 2) a = a > 0.f ? a : expm1f(a);
@@ -136,13 +137,14 @@ __global__ void g_loss_kernel(const float* __restrict__ ce, int B, const float* 
 __global__ void conv1_bwd_kernel(const float* __restrict__ dC, int L, int Cout, const float* __restrict__ W,
                                  float* __restrict__ dX, int lddx) {
     extern __shared__ float sm[];
-    float* ds = sm;                    // [71][Cout]
-    float* ws = sm + 71 * Cout;        // [Cout][8]
+    const int CS = Cout + 1;           // padded row: the 16 positions a wave reads per channel fall in 16 banks
+    float* ds = sm;                    // [71][Cout + 1]
+    float* ws = sm + 71 * CS;          // [Cout][8]
     const int b = blockIdx.y, l0 = blockIdx.x * 64, tid = threadIdx.x;
     for (int i = tid; i < 71 * Cout; i += blockDim.x) {
         const int r = i / Cout, co = i - r * Cout;
         const int l = l0 - 4 + r;
-        ds[i] = (l >= 0 && l < L) ? dC[((long)b * L + l) * Cout + co] : 0.f;
+        ds[r * CS + co] = (l >= 0 && l < L) ? dC[((long)b * L + l) * Cout + co] : 0.f;
     }
     for (int i = tid; i < Cout * 8; i += blockDim.x) ws[i] = W[i];
     __syncthreads();
@@ -153,7 +155,7 @@ __global__ void conv1_bwd_kernel(const float* __restrict__ dC, int L, int Cout, 
 #pragma unroll
         for (int t = 0; t < 8; ++t) {
             // source row l - t + 3  ->  local row (li - t + 3) + 4
-            a = __fmaf_rn(ws[co * 8 + t], ds[(li - t + 7) * Cout + co], a);
+            a = __fmaf_rn(ws[co * 8 + t], ds[(li - t + 7) * CS + co], a);
         }
     }
     a += __shfl_xor(a, 1, 64);
@@ -216,7 +218,7 @@ int wfd_g_loss(const float* ce, int B, const float* head, float alpha, float* ou
 
 int wfd_df_conv1_bwd(const float* dC, int Bn, int L, int Cout, const float* W, float* dX, int lddx, void* stream) {
     if (!dC || !W || !dX || Cout > 64) return WFD_ERR_ARG;
-    const size_t sm = (size_t)(71 * Cout + 8 * Cout) * sizeof(float);
+    const size_t sm = (size_t)(71 * (Cout + 1) + 8 * Cout) * sizeof(float);
     hipLaunchKernelGGL(conv1_bwd_kernel, dim3(cdiv(L, 64), Bn), dim3(256), sm, (hipStream_t)stream, dC, L, Cout, W, dX,
                        lddx);
     WFD_CHECK_LAUNCH();
