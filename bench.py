@@ -307,6 +307,18 @@ def main():
         barrier()
         sdt16 = parallel.max_over_ranks(time.perf_counter() - t1, device)
         samp["bf16_operands_traces_per_s"] = world * nchunks * chunk / sdt16
+        # and with split-bf16 contractions over the fp32 weights (products ~1e-5 relative)
+        bs3 = BulkSampler(eng.generator_state(), args.seq_len, args.classes, args.latent_dim, dmin, dmax, chunk=chunk,
+                          device=device, seed=99 + rank, operands="bf16x3")
+        bs3.capture()
+        for _ in range(2):
+            bs3.run_chunk(labels)
+        barrier()
+        t1 = time.perf_counter()
+        for _ in range(nchunks):
+            bs3.run_chunk(labels)
+        barrier()
+        samp["bf16x3_operands_traces_per_s"] = world * nchunks * chunk / parallel.max_over_ranks(time.perf_counter() - t1, device)
 
     # roofline of the contraction core in the mode that ran: f32-input MFMA 157.3 TF; bf16 MFMA 2.5 PF dense, of which
     # the split-bf16 mode spends three instructions per product term (peak / 3 in fp32-equivalent FLOP)

@@ -83,3 +83,30 @@ def test_bulk_sampler_bf16_close_to_fp32():
     dv = (o1 - o2).abs().float() * mask
     assert bool((dv <= 0.02 * rng[None, :] + 1).all())
     assert int(o2.min()) >= 0 and bool((o2[mask] >= 1).all())
+
+
+def test_bulk_sampler_split_bf16_matches_fp32():
+    """operands="bf16x3": the f32 sampler plan with split-bf16 contractions.  Generator outputs within 2e-5 of the f32
+    path; the integer bursts may differ by one only where the pre-round value sits within 2e-2 of a half-integer (burst
+    values reach ~1e3, so 2e-5 relative is ~2e-2 absolute), lengths by at most one."""
+    from oracle import wfdgan_oracle as O
+    from wfd_gan_amd.sampler import BulkSampler
+    fx = np.load(os.path.join(GOLDEN, "sampler_cfg2.npz"))
+    meta = json.loads(str(fx["meta"]))
+    S, C, Z = meta["seq_len"], meta["class_dim"], meta["latent_dim"]
+    torch.manual_seed(meta["seed"])
+    gsd = O.make_generator_state(S, C, Z)
+    z, c = torch.from_numpy(fx["z"]), torch.from_numpy(fx["c"])
+    f32 = BulkSampler(gsd, S, C, Z, fx["data_min"], fx["data_max"], chunk=128, device=DEV)
+    b3 = BulkSampler(gsd, S, C, Z, fx["data_min"], fx["data_max"], chunk=128, device=DEV, operands="bf16x3")
+    o1, l1 = f32.generate(c, z)
+    y1 = f32.y[: z.shape[0], :S].clone()
+    o2, l2 = b3.generate(c, z)
+    y2 = b3.y[: z.shape[0], :S].clone()
+    common = torch.minimum(f32.idx[: z.shape[0]], b3.idx[: z.shape[0]])
+    mask = torch.arange(S, device=DEV)[None, :] < common[:, None]
+    assert ((y1 - y2).abs() * mask).max().item() < 2e-5
+    assert (l1 - l2).abs().max().item() <= 1
+    same_len = l1 == l2
+    d = (o1[same_len] - o2[same_len]).abs()
+    assert d.max().item() <= 1 and (d != 0).float().mean().item() < 2e-2

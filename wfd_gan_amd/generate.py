@@ -42,7 +42,7 @@ def parse_args(argv=None):
     p.add_argument("--chunk", type=int, default=8192)
     p.add_argument("--seed", type=int, default=0)
     p.add_argument("--out", default=None, help="npz to write (traces int32 zero-padded, lens, labels)")
-    p.add_argument("--operands", choices=["f32", "bf16"], default="f32",
+    p.add_argument("--operands", choices=["f32", "bf16x3", "bf16"], default="f32",
                    help="f32 = exact-fp32 MFMA (parity path); bf16 = bf16-operand MFMA (about 3.7x faster, not bit-exact)")
     p.add_argument("--mode", choices=["generate", "wt", "glue", "synth"], default="generate",
                    help="integer epilogue: generate.py:59-63 (default), gan_wt.py:79-87, gan_glue.py:114-124 (signed), "

@@ -36,8 +36,8 @@ class BulkSampler:
         operands = "f32": exact-fp32 MFMA (the parity path: integers match the reference except at rounding
         boundaries); "bf16": bf16-operand MFMA for the four Linear layers (weights and hidden activations rounded to
         bf16, fp32 accumulate and epilogues) -- several times faster, values within ~1e-2 of the fp32 path."""
-        if operands not in ("f32", "bf16"):
-            raise ValueError("operands must be 'f32' or 'bf16'")
+        if operands not in ("f32", "bf16", "bf16x3"):
+            raise ValueError("operands must be 'f32', 'bf16x3' or 'bf16'")
         if mode not in POST_MODES:
             raise ValueError(f"mode must be one of {sorted(POST_MODES)}")
         self.operands, self.mode = operands, mode
@@ -85,10 +85,12 @@ class BulkSampler:
 
     def _build(self):
         S, C, Z, M = self.S, self.C, self.Z, self.M
+        # "bf16x3": the f32 plan with its contractions on the bf16 pipe as split-bf16 (gemm_mx.hip; products ~1e-5 relative)
+        mode = 2 if self.operands == "bf16x3" else 0
         pr = Plan(self.ws)
         pr.add(self.L.rng_normal_rows, ptr(self.zin), self.ldz, M, Z, self.seed & (2**64 - 1), self.state.data_ptr(), 0)
         pr.add(self.L.iter_advance, self.state.data_ptr(), (M * Z + 3) // 4, 0)
-        p = Plan(self.ws)
+        p = Plan(self.ws, gemm_mode=mode)
         p.add(self.L.onehot_rows, ptr(self.labels), M, C, ptr(self.zin), self.ldz, Z)
         if self.operands == "bf16":
             L = self.L
