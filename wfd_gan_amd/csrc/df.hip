@@ -29,7 +29,7 @@ __global__ void conv1_fwd_kernel(const float* __restrict__ X, int ldx, int xoff,
         for (int t = 0; t < 8; ++t) a = __fmaf_rn(ws[t * Cout + co], xs[li + t], a);
         a = __fmaf_rn(a, scale[co], shift[co]);
         if (act == 1) a = fmaxf(a, 0.f);
-        else if (act == 2) a = a > 0.f ? a : expm1f(a);
+        else if (act == 2) a = a > 0.f ? a : elu_expm1(a);
         Y[((long)b * L + l0 + li) * Cout + co] = a;
     }
 }

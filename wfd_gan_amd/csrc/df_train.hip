@@ -95,7 +95,7 @@ __global__ void bn_tall_combine_kernel(const float* __restrict__ part, int nchun
 
 __device__ __forceinline__ float act_f(float v, int act) {
     if (act == 1) return fmaxf(v, 0.f);
-    if (act == 2) return v > 0.f ? v : expm1f(v);
+    if (act == 2) return v > 0.f ? v : elu_expm1(v);
     return v;
 }
 

@@ -100,7 +100,7 @@ __device__ __forceinline__ void store4(float* __restrict__ p, float4 v, int nval
 }
 __device__ __forceinline__ float act_apply(float v, int act) {
     if (act == 1) return fmaxf(v, 0.f);
-    if (act == 2) return v > 0.f ? v : expm1f(v);
+    if (act == 2) return v > 0.f ? v : elu_expm1(v);
     if (act == 3) return 1.0f / (1.0f + expf(-v));
     return v;
 }

@@ -25,7 +25,7 @@ static __device__ __forceinline__ float epi_apply(const GemmArgs& g, float v, in
         const float sh = g.shift ? g.shift[col] : 0.f;
         v = g.scale ? __fmaf_rn(v, g.scale[col], sh) : v + sh;
         if (g.act == 1) v = fmaxf(v, 0.f);
-        else if (g.act == 2) v = v > 0.f ? v : expm1f(v);
+        else if (g.act == 2) v = v > 0.f ? v : elu_expm1(v);
         else if (g.act == 3) v = 1.0f / (1.0f + expf(-v));
     } else if (g.epi == 2) {
         if (g.dmode) {

@@ -306,7 +306,7 @@ int mx_launch4(const GemmArgs& g, int splits, hipStream_t st) {
 
 // ---------------------------------------------------------------------------------------------------------------
 // k=8 "SAME" conv over a long channels-last sequence with few channels (the DF observer's first two blocks: Cin, Cout in
-// {32, 64}, M = B*L rows): on the bf16 pipe the arithmetic is negligible and the implicit-GEMM form above is bound by
+// {32, 64}, M = B*L rows; a workgroup owns COUT of the output columns): on the bf16 pipe the arithmetic is negligible and the implicit-GEMM form above is bound by
 // re-reading every activation row eight times (once per tap).  Here a workgroup keeps the whole weight matrix
 // [Cout][8*Cin] in LDS as bf16 for its lifetime and walks `cpw` consecutive chunks of 128 output rows: a chunk's
 // 128 + 7 input rows are loaded once (contiguous, register-prefetched one chunk ahead), converted, and the A fragment of
@@ -343,10 +343,12 @@ __global__ __launch_bounds__(XT) void conv8_lds_mx_kernel(GemmArgs g, int cpw, i
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, i = lane & 31, h = lane >> 5;
     const int pad = g.convPad, L = g.convL;
     const int c0 = blockIdx.x * cpw, c1 = min(nchunks, c0 + cpw);
+    const int n0 = blockIdx.y * COUT;             // COUT = output columns of this workgroup (a slice of g.N)
 
     for (int c = tid; c < COUT * 2 * CIN; c += XT) {           // weights: COUT rows x 8*CIN floats, float4 granules
         const int r = c / (2 * CIN), q = c % (2 * CIN);
-        cv_put<TERMS>(ws, C_::W_IMG, r * C_::WS + 4 * q, *reinterpret_cast<const float4*>(g.B + (long)r * (8 * CIN) + 4 * q));
+        cv_put<TERMS>(ws, C_::W_IMG, r * C_::WS + 4 * q,
+                      *reinterpret_cast<const float4*>(g.B + (long)(n0 + r) * (8 * CIN) + 4 * q));
     }
     float4 rx[C_::XLD];
     auto load_x = [&](int chunk) {
@@ -405,7 +407,7 @@ __global__ __launch_bounds__(XT) void conv8_lds_mx_kernel(GemmArgs g, int cpw, i
         }
 #pragma unroll
         for (int b = 0; b < NA; ++b) {
-            const int col = 32 * b + i;
+            const int col = n0 + 32 * b + i;
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int row = m0 + wave * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
@@ -431,8 +433,8 @@ int cv_launch2(const GemmArgs& g, hipStream_t st) {
     int cpw = nchunks / 1024;                     // amortise the weight staging once the chip is covered four times over
     if (cpw < 1) cpw = 1;
     if (cpw > 8) cpw = 8;
-    hipLaunchKernelGGL((conv8_lds_mx_kernel<CIN, COUT, TERMS, EPI>), dim3(cdiv(nchunks, cpw)), dim3(XT), C_::LDS, st, g, cpw,
-                       nchunks);
+    hipLaunchKernelGGL((conv8_lds_mx_kernel<CIN, COUT, TERMS, EPI>), dim3(cdiv(nchunks, cpw), g.N / COUT), dim3(XT), C_::LDS,
+                       st, g, cpw, nchunks);
     WFD_CHECK_LAUNCH();
     return WFD_OK;
 }
@@ -440,8 +442,7 @@ int cv_launch2(const GemmArgs& g, hipStream_t st) {
 template <int CIN, int COUT>
 int cv_launch(const GemmArgs& g, int terms, hipStream_t st) {
     if (terms == 1) return g.epi ? cv_launch2<CIN, COUT, 1, true>(g, st) : cv_launch2<CIN, COUT, 1, false>(g, st);
-    if constexpr (CIN == 64 && COUT == 64) return WFD_ERR_ARG;         // two weight images do not fit in LDS
-    else return g.epi ? cv_launch2<CIN, COUT, 2, true>(g, st) : cv_launch2<CIN, COUT, 2, false>(g, st);
+    return g.epi ? cv_launch2<CIN, COUT, 2, true>(g, st) : cv_launch2<CIN, COUT, 2, false>(g, st);
 }
 
 template <bool AKC, bool BKC, bool IM2COL, int TERMS, bool EPI>
@@ -469,14 +470,14 @@ int mx_launch2(const GemmArgs& g, int splits, int terms, hipStream_t st) {
 // the f32-operand core otherwise).
 bool wfd_mx_conv_direct(int M, int Cin, int Cout, int terms) {
     if (!((Cin == 32 || Cin == 64) && (Cout == 32 || Cout == 64))) return false;
-    if (terms == 2 && Cin == 64 && Cout == 64) return false;
     return cdiv(M, CV_ROWS) >= 256;               // enough 128-row chunks to give every CU one
 }
 
 int wfd_mx_launch(const GemmArgs& g, int layout, int splits, int terms, hipStream_t st) {
     if (layout == 3 && splits == 1 && wfd_mx_conv_direct(g.M, g.convCin, g.N, terms) && g.ldb == 8 * g.convCin) {
         if (g.convCin == 32) return g.N == 32 ? cv_launch<32, 32>(g, terms, st) : cv_launch<32, 64>(g, terms, st);
-        return g.N == 32 ? cv_launch<64, 32>(g, terms, st) : cv_launch<64, 64>(g, terms, st);
+        // 64 -> 64: the whole weight matrix (66 KB as bf16) would leave one workgroup per CU; two 32-column slices keep three
+        return cv_launch<64, 32>(g, terms, st);
     }
     switch (layout) {
         case 0: return mx_launch2<true, true, false>(g, splits, terms, st);
