@@ -46,6 +46,14 @@ int wfd_gemm_pick_splits_mode(int M, int N, int K, int mode);
 int wfd_gemm_f32(int layout, const float* A, int lda, const float* B, int ldb, float* P, int ldp, long slab_stride,
                  int M, int N, int K, int splits, void* stream);
 
+/* Two INDEPENDENT products of the backward in one launch: problem 1 = a weight gradient (layout 2, TN, written in full to
+ * P1), problem 2 = the next activation-gradient product of the chain (layout2 0 = NT or 1 = NN, into splits2 slabs) --
+ * the pairs of src/mlp_df_wgan_train.py:229,273 that autograd also runs independently.  f32 operand mode only, 16-byte
+ * aligned operands, leading dimensions multiples of 4, N > 32; returns 1 otherwise (launch them one by one then). */
+int wfd_gemm_f32_pair(const float* A1, int lda1, const float* B1, int ldb1, float* P1, int ldp1, int M1, int N1, int K1,
+                      int layout2, const float* A2, int lda2, const float* B2, int ldb2, float* P2, int ldp2,
+                      long slab_stride2, int M2, int N2, int K2, int splits2, void* stream);
+
 /* k=8 stride-1 "SAME" Conv1d over a channels-last activation X[B][L][Cin] as an implicit GEMM,
  * P[b*L+l][co] = sum_{t,ci} X[b][l+t-pad][ci] * Wp[co][t*Cin+ci]; pad 3 = forward (src/model.py:92-105, F.pad
  * left 3 / right 4 + nn.Conv1d), pad 4 with tap-flipped transposed weights = its input gradient (:273). */

@@ -185,3 +185,33 @@ def test_gemm_nt_tall_tile(shape):
     got = out[:, :N].cpu().double()
     assert torch.isfinite(got).all()
     assert (got - want).abs().max().item() / want.abs().max().item() < 2e-5
+
+
+@pytest.mark.parametrize("lay2", [0, 1])
+def test_gemm_pair_equals_separate_launches(lay2):
+    """wfd_gemm_f32_pair (a TN weight gradient and an independent NT / NN product in one grid) runs the same tile code as
+    the two separate launches: bit-identical outputs, ragged shapes included."""
+    from wfd_gan_amd._lib import lib
+    L = lib()
+    dev = "cuda:0"
+    g = torch.Generator().manual_seed(11)
+    for (M1, N1, K1), (M2, N2, K2), ns in [((300, 200, 96), (70, 130, 333), 3), ((2048, 1501, 256), (128, 2048, 1401), 8),
+                                           ((64, 64, 64), (1, 33, 40), 1)]:
+        pad = lambda n: (n + 3) // 4 * 4
+        A1, B1 = torch.randn(K1, pad(M1), generator=g).to(dev), torch.randn(K1, pad(N1), generator=g).to(dev)
+        A2 = torch.randn(M2, pad(K2), generator=g).to(dev)
+        B2 = (torch.randn(N2, pad(K2), generator=g) if lay2 == 0 else torch.randn(K2, pad(N2), generator=g)).to(dev)
+        ldp1, ldp2 = pad(N1), pad(N2)
+        Pa, Pb = torch.zeros(M1, ldp1, device=dev), torch.zeros(M1, ldp1, device=dev)
+        Sa, Sb = torch.zeros(ns, M2, ldp2, device=dev), torch.zeros(ns, M2, ldp2, device=dev)
+        st = torch.cuda.current_stream().cuda_stream
+        L.gemm_f32(2, A1.data_ptr(), A1.shape[1], B1.data_ptr(), B1.shape[1], Pa.data_ptr(), ldp1, 0, M1, N1, K1, 1, st)
+        L.gemm_f32(lay2, A2.data_ptr(), A2.shape[1], B2.data_ptr(), B2.shape[1], Sa.data_ptr(), ldp2, M2 * ldp2, M2, N2, K2,
+                   ns, st)
+        L.gemm_f32_pair(A1.data_ptr(), A1.shape[1], B1.data_ptr(), B1.shape[1], Pb.data_ptr(), ldp1, M1, N1, K1, lay2,
+                        A2.data_ptr(), A2.shape[1], B2.data_ptr(), B2.shape[1], Sb.data_ptr(), ldp2, M2 * ldp2, M2, N2, K2,
+                        ns, st)
+        torch.cuda.synchronize()
+        assert torch.equal(Pa, Pb) and torch.equal(Sa, Sb)
+        ref = A1[:, :M1].double().T @ B1[:, :N1].double()
+        assert (Pb[:, :N1].double() - ref).abs().max().item() / ref.abs().max().item() < 2e-5

@@ -21,6 +21,19 @@
 namespace {
 
 constexpr int BM = 64, BN = 64, BK = 32, NTHREADS = 256;
+
+// Diagnostic build only (make stamps -> libwfdgan_stamps.so, tools/gemm_stamps.py): per-workgroup s_memrealtime stamps
+// (100 MHz) at entry, after the first tile is in LDS, after the k-loop and after the stores, written to the otherwise
+// unused GemmArgs::D of a raw (EPI = false) launch.  The product library is built without WFD_STAMPS: no stamp executes.
+#ifdef WFD_STAMPS
+#define WFD_STAMP(slot)                                                                                         \
+    if (!EPI && g.D && threadIdx.x == 0) {                                                                       \
+        const long wg_ = (long)bz * 65536 + (long)by * 256 + bx;                                                 \
+        reinterpret_cast<unsigned long long*>(const_cast<float*>(g.D))[(wg_ % g.ldd) * 4 + slot] = __builtin_amdgcn_s_memrealtime(); \
+    }
+#else
+#define WFD_STAMP(slot)
+#endif
 constexpr int LDK = BK + 4;  // row stride of a k-contiguous tile  [64][36]
 constexpr int LDM = BM + 4;  // row stride of an m-contiguous tile [32][68]
 constexpr int TILE_F = 64 * LDK;  // 2304 floats >= 32*68 = 2176
@@ -195,13 +208,12 @@ __device__ __forceinline__ f32x4 read_frag(const float* __restrict__ S, int row0
 // NARROW / EPI are compile-time so that the plain path keeps its instruction schedule (a runtime branch inside the
 // k-loop made hipcc stop hoisting the next tile's global loads above the MFMA block).
 template <bool AKC, bool BKC, int VA, int VB, bool IM2COL, bool NARROW, bool EPI>
-__global__ __launch_bounds__(NTHREADS) void gemm_f32_kernel(GemmArgs g) {
-    __shared__ __attribute__((aligned(16))) float lds[4 * TILE_F];
-    // buffer c: A tile at lds + 2c*TILE_F, B tile right behind it
+__device__ __forceinline__ void gemm_f32_body(const GemmArgs& g, float* __restrict__ lds, int bx, int by, int bz) {
+    // lds: 4 * TILE_F floats; buffer c: A tile at lds + 2c*TILE_F, B tile right behind it
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1, i = lane & 31, h = lane >> 5;
-    const int m0 = blockIdx.y * BM, n0 = blockIdx.x * (NARROW ? 32 : BN), z = blockIdx.z;
+    const int m0 = by * BM, n0 = bx * (NARROW ? 32 : BN), z = bz;
     // narrow: wave column index = half of the k-tile it multiplies (kk 0-1 / 2-3), both on columns n0..n0+31
     const int bcol0 = NARROW ? 0 : wn * 32;
     const int kbeg = z * g.ktiles_per_split * BK;
@@ -212,6 +224,7 @@ __global__ __launch_bounds__(NTHREADS) void gemm_f32_kernel(GemmArgs g) {
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[r] = 0.f;
 
+    WFD_STAMP(0)
     float ra[8], rb[8];
     constexpr bool FAST = (VA == 4 && VB == 4);
     int offa[2], offb[2], lpa[2], lpb[2];
@@ -240,6 +253,7 @@ __global__ __launch_bounds__(NTHREADS) void gemm_f32_kernel(GemmArgs g) {
         store_tile<BKC, VB>(rb, lds + TILE_F, tid);
     }
     __syncthreads();
+    WFD_STAMP(1)
     int cur = 0;
     for (int kt = 0; kt < nk; ++kt) {
         const bool more = kt + 1 < nk;
@@ -271,6 +285,7 @@ __global__ __launch_bounds__(NTHREADS) void gemm_f32_kernel(GemmArgs g) {
         cur ^= 1;
     }
 
+    WFD_STAMP(2)
     // C/D map of the 32x32 accumulator: col = lane & 31, row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)
     float* P = g.P + (long)z * g.slab_stride;
     if constexpr (NARROW) {
@@ -295,6 +310,47 @@ __global__ __launch_bounds__(NTHREADS) void gemm_f32_kernel(GemmArgs g) {
                 else P[(long)row * g.ldp + col] = acc[r];
             }
         }
+    }
+#ifdef WFD_STAMPS
+    __builtin_amdgcn_s_waitcnt(0);     // the stores have left the wave (vmcnt 0) before the last stamp
+#endif
+    WFD_STAMP(3)
+}
+
+#ifdef WFD_STAMPS
+}  // namespace
+// diagnostic entry: a raw wfd_gemm_f32-style launch whose workgroups write their stamps to `stamps` (nwg x 4 u64)
+extern "C" int wfd_gemm_f32_stamped(int layout, const float* A, int lda, const float* B, int ldb, float* P, int ldp,
+                                    long slab_stride, int M, int N, int K, int splits, unsigned long long* stamps, int nwg,
+                                    void* stream);
+namespace {
+#endif
+
+template <bool AKC, bool BKC, int VA, int VB, bool IM2COL, bool NARROW, bool EPI>
+__global__ __launch_bounds__(NTHREADS) void gemm_f32_kernel(GemmArgs g) {
+    __shared__ __attribute__((aligned(16))) float lds[4 * TILE_F];
+    gemm_f32_body<AKC, BKC, VA, VB, IM2COL, NARROW, EPI>(g, lds, blockIdx.x, blockIdx.y, blockIdx.z);
+}
+
+// Two INDEPENDENT products in one launch (a weight gradient beside the next step of the backward chain).  At batch 64
+// every workgroup of a GEMM launch is resident at once, so its first-tile load latency and its final store burst overlap
+// nobody's main loop (about half of the launch: DESIGN.md section 6); sharing a grid lets one product's fill / drain
+// overlap the other's MFMA work without the cross-stream hand-offs a two-stream schedule costs.  The workgroups of the
+// smaller product are spread evenly through the block order.  Problem 1: layout (A1KC, B1KC); problem 2: (A2KC, B2KC);
+// both 16-byte aligned, raw slabs.
+struct PairDims { int gx1, gy1, nb1, gx2, gy2, nb2; };
+
+template <bool A1KC, bool B1KC, bool A2KC, bool B2KC>
+__global__ __launch_bounds__(NTHREADS) void gemm_f32_pair_kernel(GemmArgs g1, GemmArgs g2, PairDims d) {
+    __shared__ __attribute__((aligned(16))) float lds[4 * TILE_F];
+    const int id = blockIdx.x, tot = d.nb1 + d.nb2;
+    const int before = (int)((long)id * d.nb2 / tot), upto = (int)((long)(id + 1) * d.nb2 / tot);
+    if (upto > before) {                   // wave-uniform: this block belongs to problem 2
+        const int j = before, per = d.gx2 * d.gy2;
+        gemm_f32_body<A2KC, B2KC, 4, 4, false, false, false>(g2, lds, (j % per) % d.gx2, (j % per) / d.gx2, j / per);
+    } else {
+        const int j = id - before, per = d.gx1 * d.gy1;
+        gemm_f32_body<A1KC, B1KC, 4, 4, false, false, false>(g1, lds, (j % per) % d.gx1, (j % per) / d.gx1, j / per);
     }
 }
 
@@ -628,6 +684,37 @@ int wfd_gemm_f32(int layout, const float* A, int lda, const float* B, int ldb, f
     }
 }
 
+// Two independent products in one launch: problem 1 = a TN weight gradient written in full to P1 (one split), problem 2
+// = an NT (layout2 = 0) or NN (layout2 = 1) product into `splits2` slabs.  Both with 16-byte aligned operands and
+// leading dimensions that are multiples of 4 floats; returns WFD_ERR_ARG otherwise (the caller launches them one by one).
+int wfd_gemm_f32_pair(const float* A1, int lda1, const float* B1, int ldb1, float* P1, int ldp1, int M1, int N1, int K1,
+                      int layout2, const float* A2, int lda2, const float* B2, int ldb2, float* P2, int ldp2,
+                      long slab_stride2, int M2, int N2, int K2, int splits2, void* stream) {
+    if (!A1 || !B1 || !P1 || !A2 || !B2 || !P2 || M1 <= 0 || N1 <= 0 || K1 <= 0 || M2 <= 0 || N2 <= 0 || K2 <= 0) return WFD_ERR_ARG;
+    if (splits2 < 1 || ldp1 < N1 || ldp2 < N2 || (layout2 != 0 && layout2 != 1) || g_gemm_mode != 0) return WFD_ERR_ARG;
+    if (splits2 > 1 && slab_stride2 < (long)M2 * ldp2) return WFD_ERR_ARG;
+    if (lda1 < M1 || ldb1 < N1 || lda2 < K2 || ldb2 < (layout2 == 0 ? K2 : N2)) return WFD_ERR_ARG;
+    if (N1 <= 32 || N2 <= 32) return WFD_ERR_ARG;
+    const bool ok = aligned16(A1) && aligned16(B1) && aligned16(A2) && aligned16(B2) && lda1 % 4 == 0 && ldb1 % 4 == 0 &&
+                    lda2 % 4 == 0 && ldb2 % 4 == 0;
+    if (!ok || !operands_fit(2, M1, N1, K1, lda1, ldb1) || !operands_fit(layout2, M2, N2, K2, lda2, ldb2)) return WFD_ERR_ARG;
+    GemmArgs g1{}, g2{};
+    g1.A = A1; g1.B = B1; g1.P = P1; g1.M = M1; g1.N = N1; g1.K = K1; g1.lda = lda1; g1.ldb = ldb1; g1.ldp = ldp1;
+    g1.ktiles_per_split = cdiv(K1, BK);
+    g2.A = A2; g2.B = B2; g2.P = P2; g2.M = M2; g2.N = N2; g2.K = K2; g2.lda = lda2; g2.ldb = ldb2; g2.ldp = ldp2;
+    g2.slab_stride = slab_stride2;
+    g2.ktiles_per_split = cdiv(cdiv(K2, BK), splits2);
+    PairDims d;
+    d.gx1 = cdiv(N1, BN); d.gy1 = cdiv(M1, BM); d.nb1 = d.gx1 * d.gy1;
+    d.gx2 = cdiv(N2, BN); d.gy2 = cdiv(M2, BM); d.nb2 = d.gx2 * d.gy2 * splits2;
+    hipStream_t st = (hipStream_t)stream;
+    dim3 grid(d.nb1 + d.nb2), block(NTHREADS);
+    if (layout2 == 0) hipLaunchKernelGGL((gemm_f32_pair_kernel<false, false, true, true>), grid, block, 0, st, g1, g2, d);
+    else hipLaunchKernelGGL((gemm_f32_pair_kernel<false, false, true, false>), grid, block, 0, st, g1, g2, d);
+    WFD_CHECK_LAUNCH();
+    return WFD_OK;
+}
+
 // "SAME" k=8 stride-1 conv as an implicit GEMM over a channels-last activation X[B][L][Cin]:
 //   P[b*L + l][co] = sum_{t,ci} X[b][l + t - pad][ci] * Wp[co][t*Cin + ci]      (zero outside [0,L))
 // pad = 3 for the forward conv (src/model.py:96-101: p = 7, left 3 / right 4) and 4 for its transposed
@@ -719,3 +806,22 @@ int wfd_conv8_wgrad_f32(const float* dY, const float* X, int Bn, int L, int Cin,
 }
 
 }  // extern "C"
+
+#ifdef WFD_STAMPS
+extern "C" int wfd_gemm_f32_stamped(int layout, const float* A, int lda, const float* B, int ldb, float* P, int ldp,
+                                    long slab_stride, int M, int N, int K, int splits, unsigned long long* stamps, int nwg,
+                                    void* stream) {
+    GemmArgs g{};
+    g.A = A; g.B = B; g.P = P; g.M = M; g.N = N; g.K = K; g.lda = lda; g.ldb = ldb; g.ldp = ldp;
+    g.slab_stride = slab_stride;
+    g.ktiles_per_split = cdiv(cdiv(K, BK), splits);
+    g.D = reinterpret_cast<const float*>(stamps); g.ldd = nwg;
+    hipStream_t st = (hipStream_t)stream;
+    switch (layout) {
+        case 0: return launch_gemm<true, true, false>(g, splits, true, true, st);
+        case 1: return launch_gemm<true, false, false>(g, splits, true, true, st);
+        case 2: return launch_gemm<false, false, false>(g, splits, true, true, st);
+        default: return WFD_ERR_ARG;
+    }
+}
+#endif

@@ -168,7 +168,7 @@ class TrainEngine:
                  seed: int = 0, workspace_mb: int = 256, process_group=None, world_size: int = 1,
                  share: Optional["TrainEngine"] = None, overlap: bool = False, force_sync: bool = False,
                  sync_bn: bool = False, rank: int = 0, stacked: Optional[Dict[str, torch.Tensor]] = None,
-                 slot: int = 0, operands: str = "f32"):
+                 slot: int = 0, operands: str = "f32", pair: bool = True):
         """Data parallel, two modes:
           * sync_bn=False (weak scaling, DDP semantics): every rank trains on its own ``batch`` rows with local
             BatchNorm statistics and a local selected-row count; gradients are averaged over ranks.
@@ -185,6 +185,9 @@ class TrainEngine:
         # contraction operands: "f32" = f32-input MFMA (exact products; the parity path), "bf16" = bf16 operands /
         # fp32 accumulate (BASELINE config 4), "bf16x3" = split-bf16 (hi*hi + hi*lo + lo*hi).  HBM stays fp32.
         self.operands, self.gemm_mode = operands, GEMM_MODES[operands]
+        # pair: a weight gradient and the next product of the backward chain (independent of each other) go out as one
+        # launch (Plan.gemm_pair) unless the two-stream schedule (overlap) is on
+        self.pair = bool(pair) and not overlap
         self.L = lib()
         self.dev = torch.device(device)
         S, C, Z, B = seq_len, class_dim, latent_dim, batch
@@ -476,6 +479,43 @@ class TrainEngine:
         # product over the stacked [penalty ; standard] rows) runs beside it on the side lane as soon as its
         # operands exist
         Dp = D.p
+        if self.pair:
+            # each layer's weight gradient (one TN product over the stacked [penalty ; standard] rows) shares a launch
+            # with the t-chain product that follows it: neither reads what the other writes
+            s = p.gemm_pair((b["DL1"], 2048, b["XC"], self.ldx, 2048, S + C, 2 * M, D.g["model.0.weight"], D.ld["model.0.weight"]),
+                            (NT, b["XC"], self.ldx, Dp["model.0.weight"], D.ld["model.0.weight"], M, 2048, S))
+            self._grad_bucket_hook(p, "D", 0)
+            p.mul(s, b["D1"], 2048, DM_MUL, None, None, b["T1H1"][:M], None, 2048)
+            s = p.gemm_pair((b["DL2"], 1024, b["T1H1"], 2048, 1024, 2048, 2 * M, D.g["model.3.weight"], 2048),
+                            (NT, b["T1H1"][:M], 2048, Dp["model.3.weight"], 2048, M, 1024, 2048))
+            self._grad_bucket_hook(p, "D", 1)
+            p.mul(s, b["D2"], 1024, DM_MUL, None, None, b["T2H2"][:M], None, 1024)
+            s = p.gemm_pair((b["DL3"], 512, b["T2H2"], 1024, 512, 1024, 2 * M, D.g["model.6.weight"], 1024),
+                            (NT, b["T2H2"][:M], 1024, Dp["model.6.weight"], 1024, M, 512, 1024))
+            p.mul(s, b["D3"], 512, DM_MUL, None, None, b["T3"], None, 512)
+        else:
+            self._d_backward_two_lane(p)
+        self._colsum_multi(p, "d_small", bias_segs + [
+            (b["T3"], 512, None, b["H3"], 512, b["DV"], M, 512, D.g["model.9.weight"]),
+            (b["DV"], 1, None, None, 0, None, M, 1, D.g["model.9.bias"]),
+            # loss scalars of :215-227 as weighted column sums of the per-row critic scores / penalties:
+            # dstats = [d_loss, penalty, w_dist, mean_rv, mean_fv]; dacc += [d_loss, w_dist] (epoch sums)
+            (b["V"], 1, b["DV"], b["PEN"], 1, b["PW"], M, 1, b["dstats"][0:1], b["dacc"][0:1]),
+            (b["PEN"], 1, b["INVB"], None, 0, None, M, 1, b["dstats"][1:2]),
+            (b["V"], 1, b["NDV"], None, 0, None, M, 1, b["dstats"][2:3], b["dacc"][1:2]),
+            (b["V"], 1, b["RSELR"], None, 0, None, M, 1, b["dstats"][3:4]),
+            (b["V"], 1, b["RSELF"], None, 0, None, M, 1, b["dstats"][4:5])])
+        p.join()
+        self._grad_sync_hook(p, "D")
+        p.add(self.L.rmsprop, ptr(D.flat), ptr(D.grad), ptr(D.sq), D.numel, self.lr, 0.99, 1e-8, self.gscale,
+              st if fast else 0, self._rng_inc() if fast else 0, (self.cursor_step if own_cursor else 0) if fast else 0)
+        return p
+
+    def _d_backward_two_lane(self, p: Plan):
+        """The same backward with every product its own launch: weight gradients on the side lane (overlap=True runs it
+        on a second stream), the t-chain on the main lane."""
+        B, M, S, C, b, D = self.B, self.M, self.S, self.C, self.buf, self.Dp
+        Dp = D.p
         p.fork()
         with p.side():
             p.gemm(TN, b["DL1"], 2048, b["XC"], self.ldx, 2048, S + C, 2 * M, out=D.g["model.0.weight"],
@@ -494,21 +534,6 @@ class TrainEngine:
             p.gemm(TN, b["DL3"], 512, b["T2H2"], 1024, 512, 1024, 2 * M, out=D.g["model.6.weight"], ldp=1024)
         s = p.gemm(NT, b["T2H2"][:M], 1024, Dp["model.6.weight"], 1024, M, 512, 1024)
         p.mul(s, b["D3"], 512, DM_MUL, None, None, b["T3"], None, 512)
-        self._colsum_multi(p, "d_small", bias_segs + [
-            (b["T3"], 512, None, b["H3"], 512, b["DV"], M, 512, D.g["model.9.weight"]),
-            (b["DV"], 1, None, None, 0, None, M, 1, D.g["model.9.bias"]),
-            # loss scalars of :215-227 as weighted column sums of the per-row critic scores / penalties:
-            # dstats = [d_loss, penalty, w_dist, mean_rv, mean_fv]; dacc += [d_loss, w_dist] (epoch sums)
-            (b["V"], 1, b["DV"], b["PEN"], 1, b["PW"], M, 1, b["dstats"][0:1], b["dacc"][0:1]),
-            (b["PEN"], 1, b["INVB"], None, 0, None, M, 1, b["dstats"][1:2]),
-            (b["V"], 1, b["NDV"], None, 0, None, M, 1, b["dstats"][2:3], b["dacc"][1:2]),
-            (b["V"], 1, b["RSELR"], None, 0, None, M, 1, b["dstats"][3:4]),
-            (b["V"], 1, b["RSELF"], None, 0, None, M, 1, b["dstats"][4:5])])
-        p.join()
-        self._grad_sync_hook(p, "D")
-        p.add(self.L.rmsprop, ptr(D.flat), ptr(D.grad), ptr(D.sq), D.numel, self.lr, 0.99, 1e-8, self.gscale,
-              st if fast else 0, self._rng_inc() if fast else 0, (self.cursor_step if own_cursor else 0) if fast else 0)
-        return p
 
     def _colsum_multi(self, p: Plan, name: str, segs):
         """segs: (X, ldx, rowscale, X2, ldx2, rowscale2, M, N, out) -> one launch of wfd_colsum_multi."""
@@ -627,23 +652,18 @@ class TrainEngine:
               ptr(self.fake_rows), self.ldx, ptr(b["idx"]), ptr(b["GDZ4"]), self.lds4, ptr(G.g["model.8.bias"]))
         # generator backward: the activation-gradient chain on the main lane, each weight gradient on the side lane
         Gp = G.p
-        p.fork()
-        with p.side():
-            p.gemm(TN, b["GDZ4"], self.lds4, b["GH3"], 2048, S, 2048, B, out=G.g["model.8.weight"], ldp=2048)
+        # (weight gradient of layer k) and (activation gradient into layer k - 1) both read dz_k only: one launch each pair
+        pr = self.pair
+        s = p.gemm_pair((b["GDZ4"], self.lds4, b["GH3"], 2048, S, 2048, B, G.g["model.8.weight"], 2048),
+                        (NN, b["GDZ4"], self.lds4, Gp["model.8.weight"], 2048, B, 2048, S), pair=pr)
         self._grad_bucket_hook(p, "G", 0)
-        prev_dz, kdz, wkey = b["GDZ4"], S, "model.8.weight"
-        lddz = self.lds4
-        for i, lin, bn, n, hin, kin in ((3, "model.5", "model.6", 2048, b["GH2"], 1024),
-                                        (2, "model.2", "model.3", 1024, b["GH1"], 512)):
-            s = p.gemm(NN, prev_dz, lddz, Gp[wkey], n, B, n, kdz)
-            self._bn_bwd(p, s, i, lin, bn, n)
-            p.fork()
-            with p.side():
-                p.gemm(TN, b[f"GDZ{i}"], n, hin, kin, n, kin, B, out=G.g[f"{lin}.weight"], ldp=kin)
-            if i == 3:
-                self._grad_bucket_hook(p, "G", 1)
-            prev_dz, kdz, wkey, lddz = b[f"GDZ{i}"], n, f"{lin}.weight", n
-        s = p.gemm(NN, prev_dz, 1024, Gp["model.2.weight"], 512, B, 512, 1024)
+        self._bn_bwd(p, s, 3, "model.5", "model.6", 2048)
+        s = p.gemm_pair((b["GDZ3"], 2048, b["GH2"], 1024, 2048, 1024, B, G.g["model.5.weight"], 1024),
+                        (NN, b["GDZ3"], 2048, Gp["model.5.weight"], 1024, B, 1024, 2048), pair=pr)
+        self._grad_bucket_hook(p, "G", 1)
+        self._bn_bwd(p, s, 2, "model.2", "model.3", 1024)
+        s = p.gemm_pair((b["GDZ2"], 1024, b["GH1"], 512, 1024, 512, B, G.g["model.2.weight"], 512),
+                        (NN, b["GDZ2"], 1024, Gp["model.2.weight"], 512, B, 512, 1024), pair=pr)
         p.mul(s, b["GH1"], 512, DM_RELU, None, None, b["GDZ1"], None, 512)
         p.add(self.L.colsum, ptr(b["GDZ1"]), 512, B, 512, 0, ptr(G.g["model.0.bias"]), 0)
         p.gemm(TN, b["GDZ1"], 512, b["ZIN"], self.ldz, 512, Z + C, B, out=G.g["model.0.weight"],

@@ -183,6 +183,30 @@ class Plan:
         self.add(self.L.gemm_f32, layout, ptr(A), lda, ptr(B), ldb, ptr(self.ws), ldp, ss, M, N, K, ns)
         return Slabs(ptr(self.ws), ns, ss, ldp, M, N)
 
+    def gemm_pair(self, tn, other, pair: bool = True) -> Slabs:
+        """A weight gradient and the next product of the backward chain, which do not depend on each other, as ONE launch
+        (wfd_gemm_f32_pair): tn = (A, lda, B, ldb, M, N, K, out, ldp) is the TN product written straight to ``out``;
+        other = (layout, A, lda, B, ldb, M, N, K) goes to slabs, which are returned.  Falls back to two launches where
+        the pair kernel does not apply (bf16-pipe modes, unaligned operands, narrow N, a K-split weight gradient)."""
+        A1, lda1, B1, ldb1, M1, N1, K1, out, ldp1 = tn
+        lay, A2, lda2, B2, ldb2, M2, N2, K2 = other
+        al = lambda x, ld: ptr(x) % 16 == 0 and ld % 4 == 0
+        ok = (pair and self.gemm_mode == 0 and lay in (NT, NN) and N1 > 32 and N2 > 32 and K1 < 1024 and al(A1, lda1)
+              and al(B1, ldb1) and al(A2, lda2) and al(B2, ldb2))
+        if not ok:
+            self.gemm(TN, A1, lda1, B1, ldb1, M1, N1, K1, out=out, ldp=ldp1)
+            return self.gemm(lay, A2, lda2, B2, ldb2, M2, N2, K2)
+        ldp2 = rup(N2, 4)
+        ns = self.pick_splits(M2, N2, K2)
+        ss = M2 * ldp2
+        while ns > 1 and ns * ss > self.ws_floats:
+            ns -= 1
+        if ns * ss > self.ws_floats:
+            raise RuntimeError(f"slab workspace too small: need {ns * ss} floats, have {self.ws_floats}")
+        self.add(self.L.gemm_f32_pair, ptr(A1), lda1, ptr(B1), ldb1, ptr(out), ldp1, M1, N1, K1, lay, ptr(A2), lda2, ptr(B2),
+                 ldb2, ptr(self.ws), ldp2, ss, M2, N2, K2, ns)
+        return Slabs(ptr(self.ws), ns, ss, ldp2, M2, N2)
+
     def conv8(self, X, Bn: int, L: int, Cin: int, pad: int, Wp, Cout: int) -> Slabs:
         M, K = Bn * L, 8 * Cin
         ldp = rup(Cout, 4)
