@@ -157,6 +157,12 @@ int wfd_bn_bwd(const float* P, int ns, long ss, int ldp, int M, int N, const flo
                const float* gamma, const float* invstd, float count, float* sums, float* DZ, int lddz, float* dgamma,
                float* dbeta, float* dbias, int phase, void* stream);
 
+/* wfd_bn_bwd with phase = 3 for a tall batch (large-batch steps): row chunks of 128 in parallel, partial sums combined
+ * in chunk order (deterministic); part = scratch of 2 * ceil(M / 128) * N floats */
+int wfd_bn_bwd_tall(const float* P, int ns, long ss, int ldp, int M, int N, const float* H, const float* XH, int ldh,
+                    const float* gamma, const float* invstd, float count, float* sums, float* DZ, int lddz, float* dgamma,
+                    float* dbeta, float* dbias, float* part, void* stream);
+
 /* Generator output: nn.Sigmoid + learned-length tail mask, src/model.py:33,42-47 (replaces zeros_like / index
  * scatter / cumsum / mul).  idx[m] = trunc(y0*range + smin) + 1; *err |= 1 where the reference would raise
  * IndexError (idx >= S). */

@@ -706,6 +706,125 @@ __global__ void g_out_bwd_kernel(const float* __restrict__ P, int ns, long ss, i
     if (j < S && threadIdx.y == 0) dbias[j] = sb;
 }
 
+// ---- BatchNorm over a tall batch (M > 128 rows: the large-batch steps of BASELINE config 4) ------------------------
+// The column-per-thread kernels above walk all M rows from N / 32 workgroups; here the rows are cut into chunks of
+// TALL_ROWS, a (64-column x chunk) workgroup produces the chunk's partial statistics, and one thread per column
+// combines the chunks in order (Chan's pairwise update for mean / M2, plain ordered sums for the backward), so the
+// result is deterministic and every access is a coalesced 256-byte row segment.
+constexpr int TALL_ROWS = 128, TALL_C = 64, TALL_R = 4;
+
+__device__ __forceinline__ float tall_reduce(float v, float (*red)[TALL_C]) {
+    __syncthreads();
+    red[threadIdx.y][threadIdx.x] = v;
+    __syncthreads();
+    float r = 0.f;
+#pragma unroll
+    for (int g = 0; g < TALL_R; ++g) r += red[g][threadIdx.x];
+    return r;
+}
+
+// z = slab sum + bias -> Z (parked);  part[(2 c) N + n] = chunk mean, part[(2 c + 1) N + n] = chunk M2
+__global__ void bn_tallf_stats_kernel(const float* __restrict__ P, int ns, long ss, int ldp, int M, int N,
+                                      const float* __restrict__ bias, float* __restrict__ Z, int ldz,
+                                      float* __restrict__ part) {
+    __shared__ float red[TALL_R][TALL_C];
+    const int n = blockIdx.x * TALL_C + threadIdx.x, c = blockIdx.y;
+    const int m0 = c * TALL_ROWS, m1 = min(M, m0 + TALL_ROWS);
+    const bool ok = n < N;
+    const float b = ok && bias ? bias[n] : 0.f;
+    float s = 0.f;
+    if (ok)
+        for (int m = m0 + threadIdx.y; m < m1; m += TALL_R) {
+            const float z = slab_sum(P, ns, ss, (long)m * ldp + n) + b;
+            Z[(long)m * ldz + n] = z;
+            s += z;
+        }
+    const float mu = tall_reduce(s, red) / (float)(m1 - m0);
+    float q = 0.f;
+    if (ok)
+        for (int m = m0 + threadIdx.y; m < m1; m += TALL_R) {
+            const float d = Z[(long)m * ldz + n] - mu;
+            q = __fmaf_rn(d, d, q);
+        }
+    q = tall_reduce(q, red);
+    if (ok && threadIdx.y == 0) { part[(long)(2 * c) * N + n] = mu; part[(long)(2 * c + 1) * N + n] = q; }
+}
+
+__global__ void bn_tallf_combine_kernel(const float* __restrict__ part, int M, int N, float* __restrict__ mean,
+                                        float* __restrict__ m2) {
+    const int n = blockIdx.x * blockDim.x + threadIdx.x;
+    if (n >= N) return;
+    float na = 0.f, mu = 0.f, q = 0.f;
+    for (int c = 0; c * TALL_ROWS < M; ++c) {
+        const float nb = (float)(min(M, (c + 1) * TALL_ROWS) - c * TALL_ROWS);
+        const float d = part[(long)(2 * c) * N + n] - mu, tot = na + nb;
+        mu += d * (nb / tot);
+        q += part[(long)(2 * c + 1) * N + n] + d * d * (na * nb / tot);
+        na = tot;
+    }
+    mean[n] = mu;
+    m2[n] = q;
+}
+
+// backward, pass 1: dy = sumP o [H > 0] -> DZ (parked); part[(2 c) N + n] = sum dy, part[(2 c + 1) N + n] = sum dy * xhat
+__global__ void bn_tallb_sums_kernel(const float* __restrict__ P, int ns, long ss, int ldp, int M, int N,
+                                     const float* __restrict__ H, const float* __restrict__ XH, int ldh,
+                                     float* __restrict__ DZ, int lddz, float* __restrict__ part) {
+    __shared__ float red[TALL_R][TALL_C];
+    const int n = blockIdx.x * TALL_C + threadIdx.x, c = blockIdx.y;
+    const int m0 = c * TALL_ROWS, m1 = min(M, m0 + TALL_ROWS);
+    const bool ok = n < N;
+    float s0 = 0.f, s1 = 0.f;
+    if (ok)
+        for (int m = m0 + threadIdx.y; m < m1; m += TALL_R) {
+            const long o = (long)m * ldh + n;
+            const float dy = H[o] > 0.f ? slab_sum(P, ns, ss, (long)m * ldp + n) : 0.f;
+            DZ[(long)m * lddz + n] = dy;
+            s0 += dy;
+            s1 = __fmaf_rn(dy, XH[o], s1);
+        }
+    s0 = tall_reduce(s0, red);
+    s1 = tall_reduce(s1, red);
+    if (ok && threadIdx.y == 0) { part[(long)(2 * c) * N + n] = s0; part[(long)(2 * c + 1) * N + n] = s1; }
+}
+
+// ordered sum of `nslot` interleaved partial rows: out_k[n] = sum_c part[(nslot c + k) N + n]
+__global__ void bn_tallb_combine_kernel(const float* __restrict__ part, int chunks, int nslot, int N, float* __restrict__ o0,
+                                        float* __restrict__ o1, float* __restrict__ o2, float* __restrict__ o3) {
+    const int n = blockIdx.x * blockDim.x + threadIdx.x;
+    if (n >= N) return;
+    for (int k = 0; k < nslot; ++k) {
+        float a = 0.f;
+        for (int c = 0; c < chunks; ++c) a += part[(long)(nslot * c + k) * N + n];
+        float* o = k == 0 ? o0 : o1;
+        float* oo = k == 0 ? o2 : o3;
+        if (o) o[n] = a;
+        if (oo) oo[n] = a;
+    }
+}
+
+// backward, pass 2: dz = gamma * invstd * (dy - s0 / count - xhat * s1 / count) in place in DZ; part[c N + n] = sum dz
+__global__ void bn_tallb_dz_kernel(int M, int N, const float* __restrict__ XH, int ldh, const float* __restrict__ gamma,
+                                   const float* __restrict__ invstd, float count, const float* __restrict__ sums,
+                                   float* __restrict__ DZ, int lddz, float* __restrict__ part) {
+    __shared__ float red[TALL_R][TALL_C];
+    const int n = blockIdx.x * TALL_C + threadIdx.x, c = blockIdx.y;
+    const int m0 = c * TALL_ROWS, m1 = min(M, m0 + TALL_ROWS);
+    const bool ok = n < N;
+    float sb = 0.f;
+    if (ok) {
+        const float k = gamma[n] * invstd[n], a0 = sums[n] / count, a1 = sums[N + n] / count;
+        for (int m = m0 + threadIdx.y; m < m1; m += TALL_R) {
+            const float dy = DZ[(long)m * lddz + n];
+            const float dz = k * (dy - a0 - XH[(long)m * ldh + n] * a1);
+            DZ[(long)m * lddz + n] = dz;
+            sb += dz;
+        }
+    }
+    sb = tall_reduce(sb, red);
+    if (ok && threadIdx.y == 0) part[(long)c * N + n] = sb;
+}
+
 // D-step scalars.  v rows [0,B) real, [B,2B) fake; pen rows likewise (W-div) or B interpolate rows (GP).
 // out: [0] d_loss [1] penalty [2] w_dist [3] mean_rv [4] mean_fv ; acc[0..2] += d_loss, w_dist, 1 (epoch sums)
 __global__ void d_loss_kernel(const float* __restrict__ v, const float* __restrict__ pen, int B, int npen, float invB,
@@ -867,8 +986,22 @@ int wfd_bn_train_relu(const float* P, int ns, long ss, int ldp, int M, int N, co
         WFD_CHECK_LAUNCH();
         return WFD_OK;
     }
-    hipLaunchKernelGGL(bn_train_relu_kernel, dim3(cdiv(N, CT)), dim3(CT, RG), 0, (hipStream_t)stream, P, ns, ss, ldp, M,
-                       N, bias, eps, gamma, beta, XH, H, ldo, mean, m2, invstd, rmean, rvar, momentum, nupd);
+    hipStream_t st = (hipStream_t)stream;
+    if (M <= 512) {          // up to a few row blocks the column-per-thread kernel is one launch and fast enough
+        hipLaunchKernelGGL(bn_train_relu_kernel, dim3(cdiv(N, CT)), dim3(CT, RG), 0, st, P, ns, ss, ldp, M, N, bias, eps, gamma,
+                           beta, XH, H, ldo, mean, m2, invstd, rmean, rvar, momentum, nupd);
+        WFD_CHECK_LAUNCH();
+        return WFD_OK;
+    }
+    // tall batch: chunk statistics -> ordered combine -> normalise.  z is parked in XH, the chunk partials
+    // (2 * chunks * N floats <= M * ldo) in H, which the last kernel then overwrites.
+    const int chunks = cdiv(M, TALL_ROWS);
+    hipLaunchKernelGGL(bn_tallf_stats_kernel, dim3(cdiv(N, TALL_C), chunks), dim3(TALL_C, TALL_R), 0, st, P, ns, ss, ldp, M, N,
+                       bias, XH, ldo, H);
+    hipLaunchKernelGGL(bn_tallf_combine_kernel, dim3(cdiv(N, 256)), dim3(256), 0, st, (const float*)H, M, N, mean, m2);
+    hipLaunchKernelGGL(bn_apply_relu_kernel, col_grid(N, M, 64), dim3(64), 0, st, (const float*)XH, ldo, M, N,
+                       (const float*)mean, (const float*)m2, (float)M, eps, gamma, beta, XH, H, ldo, invstd, rmean, rvar,
+                       momentum, nupd);
     WFD_CHECK_LAUNCH();
     return WFD_OK;
 }
@@ -937,6 +1070,26 @@ int wfd_bn_bwd(const float* P, int ns, long ss, int ldp, int M, int N, const flo
     }
     hipLaunchKernelGGL(bn_bwd_kernel, dim3(cdiv(N, CT)), dim3(CT, RG), 0, (hipStream_t)stream, P, ns, ss, ldp, M, N, H, XH,
                        ldh, gamma, invstd, count, sums, DZ, lddz, dgamma, dbeta, dbias, phase);
+    WFD_CHECK_LAUNCH();
+    return WFD_OK;
+}
+
+// wfd_bn_bwd (phase 3) for a tall batch: `part` = 2 * ceil(M / 128) * N floats of scratch
+int wfd_bn_bwd_tall(const float* P, int ns, long ss, int ldp, int M, int N, const float* H, const float* XH, int ldh,
+                    const float* gamma, const float* invstd, float count, float* sums, float* DZ, int lddz, float* dgamma,
+                    float* dbeta, float* dbias, float* part, void* stream) {
+    if (!P || !H || !XH || !gamma || !invstd || !sums || !DZ || !dgamma || !dbeta || !dbias || !part || M < 2) return WFD_ERR_ARG;
+    hipStream_t st = (hipStream_t)stream;
+    const int chunks = cdiv(M, TALL_ROWS);
+    const dim3 grid(cdiv(N, TALL_C), chunks), block(TALL_C, TALL_R);
+    hipLaunchKernelGGL(bn_tallb_sums_kernel, grid, block, 0, st, P, ns, ss, ldp, M, N, H, XH, ldh, DZ, lddz, part);
+    // sums = [sum dy ; sum dy * xhat]; dbeta = sum dy, dgamma = sum dy * xhat
+    hipLaunchKernelGGL(bn_tallb_combine_kernel, dim3(cdiv(N, 256)), dim3(256), 0, st, (const float*)part, chunks, 2, N, sums,
+                       sums + N, dbeta, dgamma);
+    hipLaunchKernelGGL(bn_tallb_dz_kernel, grid, block, 0, st, M, N, XH, ldh, gamma, invstd, count, (const float*)sums, DZ, lddz,
+                       part);
+    hipLaunchKernelGGL(bn_tallb_combine_kernel, dim3(cdiv(N, 256)), dim3(256), 0, st, (const float*)part, chunks, 1, N, dbias,
+                       (float*)nullptr, (float*)nullptr, (float*)nullptr);
     WFD_CHECK_LAUNCH();
     return WFD_OK;
 }

@@ -680,7 +680,11 @@ class TrainEngine:
                 ptr(G.p[f"{bn}.weight"]), ptr(b[f"istd{i}"]), float(self.Bg), ptr(b[f"bns{i}"]), ptr(b[f"GDZ{i}"]), n,
                 ptr(G.g[f"{bn}.weight"]), ptr(G.g[f"{bn}.bias"]), ptr(G.g[f"{lin}.bias"]))
         if not self.exact:
-            p.add(self.L.bn_bwd, *args, 3)
+            if self.B > 512:     # tall batch: row chunks in parallel, partial sums combined in chunk order
+                part = b.setdefault(f"bnpart{i}", torch.zeros(2 * ((self.B + 127) // 128) * n, dtype=torch.float32, device=self.dev))
+                p.add(self.L.bn_bwd_tall, *args, ptr(part))
+            else:
+                p.add(self.L.bn_bwd, *args, 3)
             return
         # exact mode: local [sum dy, sum dy*xhat] -> all-reduce -> dz with the global sums.  dgamma / dbeta come out
         # as the GLOBAL sums on every rank, so they are pre-divided by the world size before the gradient buffer
