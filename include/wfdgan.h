@@ -170,7 +170,8 @@ int wfd_ep_sigmoid_lenmask(const float* P, int ns, long ss, int ldp, int M, int 
                            float smin, float* out, int ldo, int* idx, int* err, void* stream);
 
 /* Backward through the mask and the sigmoid into the generator's last pre-activation (:273):
- * dz = [j < idx] * (dscale * sumP + dDF[j-1]) * y(1-y); dbias = column sums. */
+ * dz = [j < idx] * (dscale * sumP + dDF[j-1]) * y(1-y); dbias = column sums.  dbias may be NULL: dz only, one thread per
+ * element (tall batches; take the column sums of DZ with wfd_colsum_tall). */
 int wfd_g_out_bwd(const float* P, int ns, long ss, int ldp, int M, int S, float dscale, const float* dDF, int lddf,
                   const float* fake, int ldf, const int* idx, float* DZ, int lddz, float* dbias, void* stream);
 

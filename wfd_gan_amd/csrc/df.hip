@@ -12,7 +12,7 @@ __global__ void conv1_fwd_kernel(const float* __restrict__ X, int ldx, int xoff,
                                  const float* __restrict__ scale, const float* __restrict__ shift, int act,
                                  float* __restrict__ Y, int Cout) {
     __shared__ float xs[64 + 8];
-    __shared__ float ws[64 * 8];
+    __shared__ __attribute__((aligned(16))) float ws[64 * 8];
     const int b = blockIdx.y, l0 = blockIdx.x * 64, tid = threadIdx.x;
     if (tid < 71) {
         const int l = l0 + tid - 3;
@@ -21,16 +21,27 @@ __global__ void conv1_fwd_kernel(const float* __restrict__ X, int ldx, int xoff,
     // taps stored [t][co]: the lanes of a wave differ in co, so a tap is read from consecutive banks
     for (int i = tid; i < Cout * 8; i += blockDim.x) ws[(i & 7) * Cout + (i >> 3)] = W[i];
     __syncthreads();
-    for (int o = tid; o < 64 * Cout; o += blockDim.x) {
-        const int li = o / Cout, co = o - li * Cout;
+    // a thread produces 4 consecutive channels of one position: 16-byte stores, Cout / 4 threads per position
+    const int q4 = Cout >> 2;
+    for (int o = tid; o < 64 * q4; o += blockDim.x) {
+        const int li = o / q4, c0 = 4 * (o - li * q4);
         if (l0 + li >= L) break;
-        float a = 0.f;
+        float a[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-        for (int t = 0; t < 8; ++t) a = __fmaf_rn(ws[t * Cout + co], xs[li + t], a);
-        a = __fmaf_rn(a, scale[co], shift[co]);
-        if (act == 1) a = fmaxf(a, 0.f);
-        else if (act == 2) a = a > 0.f ? a : elu_expm1(a);
-        Y[((long)b * L + l0 + li) * Cout + co] = a;
+        for (int t = 0; t < 8; ++t) {
+            const float x = xs[li + t];
+            const float4 w = *reinterpret_cast<const float4*>(ws + t * Cout + c0);
+            a[0] = __fmaf_rn(w.x, x, a[0]); a[1] = __fmaf_rn(w.y, x, a[1]);
+            a[2] = __fmaf_rn(w.z, x, a[2]); a[3] = __fmaf_rn(w.w, x, a[3]);
+        }
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            float v = __fmaf_rn(a[k], scale[c0 + k], shift[c0 + k]);
+            if (act == 1) v = fmaxf(v, 0.f);
+            else if (act == 2) v = v > 0.f ? v : elu_expm1(v);
+            a[k] = v;
+        }
+        *reinterpret_cast<float4*>(Y + ((long)b * L + l0 + li) * Cout + c0) = make_float4(a[0], a[1], a[2], a[3]);
     }
 }
 
@@ -141,10 +152,14 @@ __global__ void conv1_bwd_kernel(const float* __restrict__ dC, int L, int Cout, 
     float* ds = sm;                    // [71][Cout + 1]
     float* ws = sm + 71 * CS;          // [Cout][8]
     const int b = blockIdx.y, l0 = blockIdx.x * 64, tid = threadIdx.x;
-    for (int i = tid; i < 71 * Cout; i += blockDim.x) {
-        const int r = i / Cout, co = i - r * Cout;
+    const int q4 = Cout >> 2;
+    for (int i = tid; i < 71 * q4; i += blockDim.x) {          // 16-byte loads, scalar stores into the padded rows
+        const int r = i / q4, c0 = 4 * (i - r * q4);
         const int l = l0 - 4 + r;
-        ds[r * CS + co] = (l >= 0 && l < L) ? dC[((long)b * L + l) * Cout + co] : 0.f;
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (l >= 0 && l < L) v = *reinterpret_cast<const float4*>(dC + ((long)b * L + l) * Cout + c0);
+        float* d = ds + r * CS + c0;
+        d[0] = v.x; d[1] = v.y; d[2] = v.z; d[3] = v.w;
     }
     for (int i = tid; i < Cout * 8; i += blockDim.x) ws[i] = W[i];
     __syncthreads();
@@ -169,7 +184,7 @@ extern "C" {
 
 int wfd_df_conv1_fwd(const float* X, int ldx, int xoff, int Bn, int L, const float* W, const float* scale,
                      const float* shift, int act, float* Y, int Cout, void* stream) {
-    if (!X || !W || !scale || !shift || !Y || Cout > 64 || Cout <= 0) return WFD_ERR_ARG;
+    if (!X || !W || !scale || !shift || !Y || Cout > 64 || Cout <= 0 || (Cout & 3)) return WFD_ERR_ARG;
     hipLaunchKernelGGL(conv1_fwd_kernel, dim3(cdiv(L, 64), Bn), dim3(256), 0, (hipStream_t)stream, X, ldx, xoff, L, W,
                        scale, shift, act, Y, Cout);
     WFD_CHECK_LAUNCH();
@@ -217,7 +232,7 @@ int wfd_g_loss(const float* ce, int B, const float* head, float alpha, float* ou
 }
 
 int wfd_df_conv1_bwd(const float* dC, int Bn, int L, int Cout, const float* W, float* dX, int lddx, void* stream) {
-    if (!dC || !W || !dX || Cout > 64) return WFD_ERR_ARG;
+    if (!dC || !W || !dX || Cout > 64 || (Cout & 3)) return WFD_ERR_ARG;
     const size_t sm = (size_t)(71 * (Cout + 1) + 8 * Cout) * sizeof(float);
     hipLaunchKernelGGL(conv1_bwd_kernel, dim3(cdiv(L, 64), Bn), dim3(256), sm, (hipStream_t)stream, dC, L, Cout, W, dX,
                        lddx);

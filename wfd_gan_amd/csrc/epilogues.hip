@@ -825,6 +825,24 @@ __global__ void bn_tallb_dz_kernel(int M, int N, const float* __restrict__ XH, i
     if (ok && threadIdx.y == 0) part[(long)c * N + n] = sb;
 }
 
+// g_out_bwd without the bias-gradient sum, one thread per (row, column): the tall-batch form (the caller takes the column
+// sums of DZ with wfd_colsum_tall)
+__global__ void g_out_dz_kernel(const float* __restrict__ P, int ns, long ss, int ldp, int M, int S, float dscale,
+                                const float* __restrict__ dDF, int lddf, const float* __restrict__ fake, int ldf,
+                                const int* __restrict__ idx, float* __restrict__ DZ, int lddz) {
+    const int j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= S) return;
+    for (int m = blockIdx.y; m < M; m += gridDim.y) {
+        float dz = 0.f;
+        if (j < idx[m]) {
+            const float y = fake[(long)m * ldf + j];
+            const float dd = (dDF && j >= 1) ? dDF[(long)m * lddf + j - 1] : 0.f;
+            dz = (dscale * slab_sum(P, ns, ss, (long)m * ldp + j) + dd) * y * (1.f - y);
+        }
+        DZ[(long)m * lddz + j] = dz;
+    }
+}
+
 // D-step scalars.  v rows [0,B) real, [B,2B) fake; pen rows likewise (W-div) or B interpolate rows (GP).
 // out: [0] d_loss [1] penalty [2] w_dist [3] mean_rv [4] mean_fv ; acc[0..2] += d_loss, w_dist, 1 (epoch sums)
 __global__ void d_loss_kernel(const float* __restrict__ v, const float* __restrict__ pen, int B, int npen, float invB,
@@ -1116,7 +1134,13 @@ int wfd_ep_sigmoid_lenmask_slots(const float* P, int ns, long ss, int ldp, int M
 
 int wfd_g_out_bwd(const float* P, int ns, long ss, int ldp, int M, int S, float dscale, const float* dDF, int lddf,
                   const float* fake, int ldf, const int* idx, float* DZ, int lddz, float* dbias, void* stream) {
-    if (!P || !fake || !idx || !DZ || !dbias) return WFD_ERR_ARG;
+    if (!P || !fake || !idx || !DZ) return WFD_ERR_ARG;
+    if (!dbias) {            // dz only, fully parallel (tall batches; the bias gradient = wfd_colsum_tall of DZ)
+        hipLaunchKernelGGL(g_out_dz_kernel, dim3(cdiv(S, 256), M < 1024 ? M : 1024), dim3(256), 0, (hipStream_t)stream, P, ns, ss,
+                           ldp, M, S, dscale, dDF, lddf, fake, ldf, idx, DZ, lddz);
+        WFD_CHECK_LAUNCH();
+        return WFD_OK;
+    }
     hipLaunchKernelGGL(g_out_bwd_kernel, dim3(cdiv(S, CT)), dim3(CT, RG), 0, (hipStream_t)stream, P, ns, ss, ldp, M, S,
                        dscale, dDF, lddf, fake, ldf, idx, DZ, lddz, dbias);
     WFD_CHECK_LAUNCH();

@@ -648,8 +648,14 @@ class TrainEngine:
             p.add(self.L.g_head, ptr(b["gV"]), B, 1.0 / self.Bg, ptr(b["ghead"]))
             g = self._critic_chain(p, B, b["gDL3"], b["gDL2"], None, b["gDL1"], None, b["gD2"], b["gD1"], None)
         self._observer(p)
-        p.add(self.L.g_out_bwd, g.ptr, g.ns, g.ss, g.ldp, B, S, -1.0 / self.Bg, ptr(b["DDF"]), self.ldl,
-              ptr(self.fake_rows), self.ldx, ptr(b["idx"]), ptr(b["GDZ4"]), self.lds4, ptr(G.g["model.8.bias"]))
+        if B > 512:      # tall batch: dz in one fully parallel pass, its column sums (the bias gradient) by row chunks
+            part = b.setdefault("gout_part", torch.zeros(((B + 127) // 128) * S, dtype=torch.float32, device=self.dev))
+            p.add(self.L.g_out_bwd, g.ptr, g.ns, g.ss, g.ldp, B, S, -1.0 / self.Bg, ptr(b["DDF"]), self.ldl,
+                  ptr(self.fake_rows), self.ldx, ptr(b["idx"]), ptr(b["GDZ4"]), self.lds4, 0)
+            p.add(self.L.colsum_tall, ptr(b["GDZ4"]), self.lds4, B, S, 128, ptr(part), ptr(G.g["model.8.bias"]))
+        else:
+            p.add(self.L.g_out_bwd, g.ptr, g.ns, g.ss, g.ldp, B, S, -1.0 / self.Bg, ptr(b["DDF"]), self.ldl,
+                  ptr(self.fake_rows), self.ldx, ptr(b["idx"]), ptr(b["GDZ4"]), self.lds4, ptr(G.g["model.8.bias"]))
         # generator backward: the activation-gradient chain on the main lane, each weight gradient on the side lane
         Gp = G.p
         # (weight gradient of layer k) and (activation gradient into layer k - 1) both read dz_k only: one launch each pair
