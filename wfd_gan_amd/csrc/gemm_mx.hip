@@ -319,7 +319,8 @@ struct ConvGeo {
     static constexpr int WS = 8 * CIN + 8, XS = CIN + 8;          // bf16 row strides: odd numbers of 16-B slots
     static constexpr int W_IMG = COUT * WS, X_IMG = (CV_ROWS + 7) * XS;
     static constexpr int XLD = ((CV_ROWS + 7) * CIN / 4 + XT - 1) / XT;   // float4 per thread per chunk
-    static constexpr size_t LDS = (size_t)TERMS * (W_IMG + X_IMG) * sizeof(__bf16);
+    static constexpr int IMG_BYTES = TERMS * (W_IMG + X_IMG) * (int)sizeof(__bf16);   // multiple of 16
+    static constexpr size_t LDS = (size_t)IMG_BYTES + (size_t)CV_ROWS * COUT * sizeof(float);   // + output staging tile
 };
 
 template <int TERMS>
@@ -334,7 +335,7 @@ __device__ __forceinline__ void cv_put(__bf16* __restrict__ S, int img, int off,
 }
 
 template <int CIN, int COUT, int TERMS, bool EPI>
-__global__ __launch_bounds__(XT) void conv8_lds_mx_kernel(GemmArgs g, int cpw, int nchunks) {
+__global__ __launch_bounds__(XT) void conv8_lds_mx_kernel(GemmArgs g, int cpw, int nchunks, int wide) {
     extern __shared__ __attribute__((aligned(16))) __bf16 smem[];
     using C_ = ConvGeo<CIN, COUT, TERMS>;
     __bf16* ws = smem;                            // [TERMS][COUT][WS]
@@ -405,15 +406,68 @@ __global__ __launch_bounds__(XT) void conv8_lds_mx_kernel(GemmArgs g, int cpw, i
                 }
             }
         }
+        if (wide) {
+            // The accumulator layout gives a lane 16 rows of one column: stored directly that is 16 dword stores per
+            // lane, two 128-byte row pieces per instruction (and the same for the D operand of the backward form).  The
+            // tile goes through LDS instead and leaves as 16-byte accesses along the rows: this kernel is HBM-bound.
+            float* os = reinterpret_cast<float*>(reinterpret_cast<char*>(smem) + C_::IMG_BYTES);     // [128][COUT]
 #pragma unroll
-        for (int b = 0; b < NA; ++b) {
-            const int col = n0 + 32 * b + i;
+            for (int b = 0; b < NA; ++b)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int row = m0 + wave * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
-                if (row < g.M) {
-                    if constexpr (EPI) g.P[(long)row * g.ldp + col] = epi_apply(g, acc[b][r], row, col);
-                    else g.P[(long)row * g.ldp + col] = acc[b][r];
+                for (int r = 0; r < 16; ++r)
+                    os[(wave * 32 + (r & 3) + 8 * (r >> 2) + 4 * h) * COUT + 32 * b + i] = acc[b][r];
+            __syncthreads();
+            constexpr int Q4 = COUT / 4;
+            for (int e = tid; e < CV_ROWS * Q4; e += XT) {
+                const int rl = e / Q4, c4 = 4 * (e % Q4), row = m0 + rl, col = n0 + c4;
+                if (row >= g.M) break;
+                float4 v = *reinterpret_cast<const float4*>(os + rl * COUT + c4);
+                if constexpr (EPI) {
+                    float o[4] = {v.x, v.y, v.z, v.w};
+                    if (g.epi == 1) {
+                        float4 sc = make_float4(1.f, 1.f, 1.f, 1.f), sh = make_float4(0.f, 0.f, 0.f, 0.f);
+                        if (g.scale) sc = *reinterpret_cast<const float4*>(g.scale + col);
+                        if (g.shift) sh = *reinterpret_cast<const float4*>(g.shift + col);
+                        const float scv[4] = {sc.x, sc.y, sc.z, sc.w}, shv[4] = {sh.x, sh.y, sh.z, sh.w};
+#pragma unroll
+                        for (int k = 0; k < 4; ++k) {
+                            float x = g.scale ? __fmaf_rn(o[k], scv[k], shv[k]) : o[k] + shv[k];
+                            if (g.act == 1) x = fmaxf(x, 0.f);
+                            else if (g.act == 2) x = x > 0.f ? x : elu_expm1(x);
+                            else if (g.act == 3) x = 1.0f / (1.0f + expf(-x));
+                            o[k] = x;
+                        }
+                    } else if (g.epi == 2) {
+                        if (g.dmode) {
+                            const float4 d4 = *reinterpret_cast<const float4*>(g.D + (long)row * g.ldd + col);
+                            const float dv[4] = {d4.x, d4.y, d4.z, d4.w};
+#pragma unroll
+                            for (int k = 0; k < 4; ++k) {
+                                if (g.dmode == 1) o[k] *= dv[k];
+                                else if (g.dmode == 2) o[k] = dv[k] > 0.f ? o[k] : 0.f;
+                                else o[k] = dv[k] > 0.f ? o[k] : o[k] * (dv[k] + 1.f);
+                            }
+                        }
+                        if (g.scale) {
+                            const float4 sc = *reinterpret_cast<const float4*>(g.scale + col);
+                            o[0] *= sc.x; o[1] *= sc.y; o[2] *= sc.z; o[3] *= sc.w;
+                        }
+                    }
+                    v = make_float4(o[0], o[1], o[2], o[3]);
+                }
+                *reinterpret_cast<float4*>(g.P + (long)row * g.ldp + col) = v;
+            }
+        } else {
+#pragma unroll
+            for (int b = 0; b < NA; ++b) {
+                const int col = n0 + 32 * b + i;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int row = m0 + wave * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+                    if (row < g.M) {
+                        if constexpr (EPI) g.P[(long)row * g.ldp + col] = epi_apply(g, acc[b][r], row, col);
+                        else g.P[(long)row * g.ldp + col] = acc[b][r];
+                    }
                 }
             }
         }
@@ -433,8 +487,12 @@ int cv_launch2(const GemmArgs& g, hipStream_t st) {
     int cpw = nchunks / 1024;                     // amortise the weight staging once the chip is covered four times over
     if (cpw < 1) cpw = 1;
     if (cpw > 8) cpw = 8;
+    // the 16-byte epilogue needs 16-byte aligned rows in everything it touches
+    auto a16 = [](const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; };
+    const int wide = a16(g.P) && g.ldp % 4 == 0 && (!g.scale || a16(g.scale)) && (!g.shift || a16(g.shift)) &&
+                     (!(g.epi == 2 && g.dmode) || (a16(g.D) && g.ldd % 4 == 0));
     hipLaunchKernelGGL((conv8_lds_mx_kernel<CIN, COUT, TERMS, EPI>), dim3(cdiv(nchunks, cpw), g.N / COUT), dim3(XT), C_::LDS,
-                       st, g, cpw, nchunks);
+                       st, g, cpw, nchunks, wide);
     WFD_CHECK_LAUNCH();
     return WFD_OK;
 }
