@@ -104,7 +104,7 @@ def gemm_roofline(eng, plans=None, rep=16, rounds=3):
     from wfd_gan_amd.plan import FORK, HOST, JOIN
     L = eng.L
     gemm_fns = {L.gemm_f32: "gemm", L.conv8_gemm_f32: "conv", L.gemm_f32_fused: "gemm_fused",
-                L.conv8_gemm_f32_fused: "conv"}
+                L.conv8_gemm_f32_fused: "conv", L.gemm_f32_pair: "pair"}
     calls = []
     for plan, weight in (plans or ((eng.fast_d, eng.n_critic), (eng.fast_g, 1))):
         for fn, a, _lane in plan.calls:
@@ -112,6 +112,9 @@ def gemm_roofline(eng, plans=None, rep=16, rounds=3):
                 continue
             kind = gemm_fns.get(fn)
             if kind is None:
+                continue
+            if kind == "pair":           # two products in one launch: their FLOPs add
+                calls.append((fn, a, 2.0 * a[6] * a[7] * a[8] + 2.0 * a[17] * a[18] * a[19], weight))
                 continue
             if kind == "gemm":
                 M, N, K = a[8], a[9], a[10]
@@ -325,7 +328,7 @@ def main():
     peak = {"f32": PEAK_F32_MFMA_TFLOPS, "bf16": 2500.0, "bf16x3": 2500.0 / 3}[args.operands]
     dtype = {"f32": "f32", "bf16": "bf16 operands, f32 accumulate (data f32 in HBM)",
              "bf16x3": "f32 via split-bf16 (3 bf16 MFMAs per product), f32 accumulate"}[args.operands]
-    core = ("fp32 MFMA core: gemm_f32_kernel (all layouts, implicit-GEMM conv) + conv8_c32_kernel" if args.operands == "f32"
+    core = ("fp32 MFMA core: gemm_f32_kernel / gemm_f32_pair_kernel (all layouts, implicit-GEMM conv) + conv8_c32_kernel" if args.operands == "f32"
             else "bf16 MFMA core over fp32 data: gemm_mx_kernel (all layouts, implicit-GEMM conv)")
     # the same step with the contractions on the bf16 matrix pipe (gemm_mx.hip): reported beside the headline, never as
     # `value` (the headline stays the f32-operand parity path unless --operands says otherwise)
