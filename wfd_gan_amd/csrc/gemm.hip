@@ -370,63 +370,90 @@ int launch_gemm2(const GemmArgs& g, int splits, bool va4, bool vb4, hipStream_t 
 // the implicit-GEMM form above re-reads every activation row eight times (once per tap) from L2 and streams the
 // weights per k-tile.  Here a workgroup keeps its 128 + 7 input rows AND the 32 x 256 weight tile in LDS
 // (19.4 + 33.3 KB), so the K loop touches no global memory and has no barrier: the A fragment of tap t is the SAME
-// LDS tile read t rows further down.  4 waves x (32 rows x 32 columns), 128 MFMAs each.
+// LDS tile read t rows further down.  4 waves x (32 rows x 32 columns), 128 MFMAs each.  A workgroup walks `cpw`
+// consecutive chunks with the weight tile kept in LDS and the next chunk's rows prefetched into registers.
 // Rows are flattened (sample, position) pairs; a tap that would cross a sample edge is zeroed per lane.
 constexpr int C32 = 32, C32_ROWS = 128, XS_LD = C32 + 4, WS_LD = 8 * C32 + 4;
 constexpr int C32_LDS_FLOATS = (C32_ROWS + 7) * XS_LD + 32 * WS_LD;
 
 template <bool EPI>
-__global__ __launch_bounds__(NTHREADS) void conv8_c32_kernel(GemmArgs g) {
+__global__ __launch_bounds__(NTHREADS) void conv8_c32_kernel(GemmArgs g, int cpw, int nchunks) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* xs = smem;                              // [135][36]  rows m0 - pad .. m0 + 127 + 7 - pad
     float* ws = smem + (C32_ROWS + 7) * XS_LD;     // [32][260]  weights of columns n0 .. n0 + 31, k-contiguous
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, i = lane & 31, h = lane >> 5;
-    const int m0 = blockIdx.x * C32_ROWS, n0 = blockIdx.y * 32, pad = g.convPad, L = g.convL;
-    for (int c = tid; c < (C32_ROWS + 7) * 8; c += NTHREADS) {
-        const int r = c >> 3, q = c & 7;
-        const long src = (long)m0 - pad + r;
-        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (src >= 0 && src < g.M) v = *reinterpret_cast<const float4*>(g.A + src * C32 + 4 * q);
-        *reinterpret_cast<float4*>(xs + r * XS_LD + 4 * q) = v;
-    }
+    const int n0 = blockIdx.y * 32, pad = g.convPad, L = g.convL;
+    // the weight tile is loaded once per workgroup and serves its `cpw` consecutive 128-row chunks
     for (int c = tid; c < 32 * 64; c += NTHREADS) {
         const int r = c >> 6, q = c & 63;
         float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
         if (n0 + r < g.N) v = *reinterpret_cast<const float4*>(g.B + (long)(n0 + r) * (8 * C32) + 4 * q);
         *reinterpret_cast<float4*>(ws + r * WS_LD + 4 * q) = v;
     }
-    __syncthreads();
-
-    const int mrow = m0 + wave * 32 + i;           // the output row whose A values this lane feeds
-    const int l = mrow < g.M ? mrow % L : -(1 << 20);
-    f32x16 acc;
+    // input rows of a chunk travel global -> registers -> LDS; the next chunk's are in flight during the MFMA block
+    constexpr int XN = (C32_ROWS + 7) * 8, XQ = (XN + NTHREADS - 1) / NTHREADS;
+    float4 xr[XQ];
+    auto load_x = [&](int chunk) {
+        const long base = (long)chunk * C32_ROWS - pad;
 #pragma unroll
-    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
-#pragma unroll
-    for (int t = 0; t < 8; ++t) {
-        const bool ok = (unsigned)(l + t - pad) < (unsigned)L;
-        const float* ap = xs + (wave * 32 + i + t) * XS_LD + 4 * h;
-        const float* bp = ws + i * WS_LD + t * C32 + 4 * h;
-#pragma unroll
-        for (int kk = 0; kk < 4; ++kk) {
-            f32x4 a = *reinterpret_cast<const f32x4*>(ap + 8 * kk);
-            const f32x4 b = *reinterpret_cast<const f32x4*>(bp + 8 * kk);
-            if (!ok) { a[0] = 0.f; a[1] = 0.f; a[2] = 0.f; a[3] = 0.f; }
-#pragma unroll
-            for (int s2 = 0; s2 < 4; ++s2) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[s2], b[s2], acc, 0, 0, 0);
+        for (int u = 0; u < XQ; ++u) {
+            const int c = tid + u * NTHREADS;
+            const long src = base + (c >> 3);
+            xr[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (c < XN && src >= 0 && src < g.M) xr[u] = *reinterpret_cast<const float4*>(g.A + src * C32 + 4 * (c & 7));
         }
-    }
-    const int col = n0 + i;
-    if (col < g.N) {
+    };
+    const int c0 = blockIdx.x * cpw, c1 = min(c0 + cpw, nchunks);
+    load_x(c0);
+    for (int ch = c0; ch < c1; ++ch) {
+        if (ch > c0) __syncthreads();              // every wave is done reading the previous chunk's rows
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int row = m0 + wave * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
-            if (row < g.M) {
-                if constexpr (EPI) g.P[(long)row * g.ldp + col] = epi_apply(g, acc[r], row, col);
-                else g.P[(long)row * g.ldp + col] = acc[r];
+        for (int u = 0; u < XQ; ++u) {
+            const int c = tid + u * NTHREADS;
+            if (c < XN) *reinterpret_cast<float4*>(xs + (c >> 3) * XS_LD + 4 * (c & 7)) = xr[u];
+        }
+        __syncthreads();
+        if (ch + 1 < c1) load_x(ch + 1);
+
+        const int m0 = ch * C32_ROWS;
+        const int mrow = m0 + wave * 32 + i;       // the output row whose A values this lane feeds
+        const int l = mrow < g.M ? mrow % L : -(1 << 20);
+        f32x16 acc;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+#pragma unroll
+        for (int t = 0; t < 8; ++t) {
+            const bool ok = (unsigned)(l + t - pad) < (unsigned)L;
+            const float* ap = xs + (wave * 32 + i + t) * XS_LD + 4 * h;
+            const float* bp = ws + i * WS_LD + t * C32 + 4 * h;
+#pragma unroll
+            for (int kk = 0; kk < 4; ++kk) {
+                f32x4 a = *reinterpret_cast<const f32x4*>(ap + 8 * kk);
+                const f32x4 b = *reinterpret_cast<const f32x4*>(bp + 8 * kk);
+                if (!ok) { a[0] = 0.f; a[1] = 0.f; a[2] = 0.f; a[3] = 0.f; }
+#pragma unroll
+                for (int s2 = 0; s2 < 4; ++s2) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[s2], b[s2], acc, 0, 0, 0);
+            }
+        }
+        const int col = n0 + i;
+        if (col < g.N) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = m0 + wave * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+                if (row < g.M) {
+                    if constexpr (EPI) g.P[(long)row * g.ldp + col] = epi_apply(g, acc[r], row, col);
+                    else g.P[(long)row * g.ldp + col] = acc[r];
+                }
             }
         }
     }
+}
+
+// chunks per workgroup: three workgroups fit a CU (LDS) and the kernel needs all three to hide its LDS / store phases
+// (measured at M = 5.7 M rows: 94 TF with 3 per CU, 83 TF with 2, 55 TF with 1), so the chunks are dealt to 768 workgroups
+inline int conv8_c32_cpw(int nchunks, int gy) {
+    const int slots = cdiv(768, gy);
+    return cdiv(nchunks, slots);
 }
 
 template <bool EPI>
@@ -437,7 +464,8 @@ int launch_conv8_c32(const GemmArgs& g, hipStream_t st) {
         (void)hipFuncSetAttribute((const void*)conv8_c32_kernel<EPI>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         attr = true;
     }
-    hipLaunchKernelGGL((conv8_c32_kernel<EPI>), dim3(cdiv(g.M, C32_ROWS), cdiv(g.N, 32)), dim3(NTHREADS), lds, st, g);
+    const int nchunks = cdiv(g.M, C32_ROWS), gy = cdiv(g.N, 32), cpw = conv8_c32_cpw(nchunks, gy);
+    hipLaunchKernelGGL((conv8_c32_kernel<EPI>), dim3(cdiv(nchunks, cpw), gy), dim3(NTHREADS), lds, st, g, cpw, nchunks);
     WFD_CHECK_LAUNCH();
     return WFD_OK;
 }
