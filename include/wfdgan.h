@@ -105,6 +105,12 @@ int wfd_ep_lrelu_drop(const float* P, int ns, long ss, int ldp, int M, int N, co
 int wfd_d_head(const float* H3, int ldh, const float* D3, int ldd, const float* w4, const float* b4, int M, int K,
                const float* rowscale, float* v, float* delta, float* delta_s, int ldo, void* stream);
 
+/* wfd_ep_lrelu_drop on the slabs of the last hidden layer (src/model.py:63-65) and wfd_d_head (:66) in one launch: same
+ * outputs (H3, D3, v, delta, delta_s), same operations in the same order, one dependent launch less per critic pass. */
+int wfd_d_head_lrelu(const float* P, int ns, long ss, int ldp, const float* bias, const float* mask, int ldmask,
+                     float slope, float* H3, int ldh, float* D3, int ldd, const float* w4, const float* b4, int M, int K,
+                     const float* rowscale, float* v, float* delta, float* delta_s, int ldo, void* stream);
+
 /* out = sumP * f(D) * colscale[n]; dmode 0 none, 1 D, 2 [D > 0] (ReLU'), 3 ELU' from its output; optional
  * out2 = out * rowscale[m].  One step of autograd.grad(validity, traces, create_graph=True) in closed form
  * (src/mlp_df_wgan_train.py:204-206) and of backward() through ReLU/ELU + folded BN (:273). */
@@ -213,6 +219,12 @@ int wfd_df_conv1_bwd(const float* dC, int Bn, int L, int Cout, const float* W, f
  * graph draws fresh numbers on every replay; wfd_iter_advance moves it. */
 int wfd_rng_dropout_mask(float* out, long n, float p, unsigned long long seed, const unsigned long long* state,
                          unsigned long long base, void* stream);
+
+/* wfd_rng_dropout_mask for up to 8 buffers in one launch (the masks of all iterations of a group of n_critic iterations,
+ * drawn ahead): `slots` is a HOST array of nslots x {device pointer, element count, seed, base}, read during the call;
+ * buffer s holds what wfd_rng_dropout_mask(out_s, n_s, p, seed_s, state, base_s) would write. */
+int wfd_rng_dropout_mask_slots(const unsigned long long* slots, int nslots, float p, const unsigned long long* state,
+                               void* stream);
 
 /* z ~ N(0,1) (np.random.normal, src/mlp_df_wgan_train.py:194; np.random.randn, src/generate.py:53) on device */
 int wfd_rng_normal_rows(float* out, int ld, int M, int Z, unsigned long long seed, const unsigned long long* state,

@@ -280,3 +280,40 @@ def test_minmax_fit_transform_on_device_is_bit_identical(shape):
     assert scaler.n_samples_seen_ == N and scaler.n_features_in_ == S
     y = rng.random((3, S)).astype(np.float32)
     assert np.array_equal(scaler.inverse_transform(y.copy()), sk.inverse_transform(y.copy()))
+
+
+@pytest.mark.parametrize("shape", [(128, 512, 8), (192, 512, 16), (7, 37, 3), (64, 512, 1)])
+def test_d_head_lrelu_equals_the_two_launches(shape):
+    """wfd_d_head_lrelu = wfd_ep_lrelu_drop on the layer-3 slabs followed by wfd_d_head, in one launch: bit-identical."""
+    from wfd_gan_amd._lib import lib
+    L = lib()
+    M, K, ns = shape
+    dev = "cuda:0"
+    g = torch.Generator().manual_seed(17)
+    ldp = (K + 3) // 4 * 4
+    P = torch.randn(ns, M, ldp, generator=g).to(dev)
+    bias, w4, b4 = torch.randn(K, generator=g).to(dev), torch.randn(K, generator=g).to(dev), torch.randn(1, generator=g).to(dev)
+    mask = ((torch.rand(M, ldp, generator=g) > 0.2).float() * 1.25).to(dev)
+    rs = torch.randn(M, generator=g).to(dev)
+    st = torch.cuda.current_stream().cuda_stream
+    outs = []
+    for fused in (False, True):
+        H, D = torch.full((M, ldp), 9.0, device=dev), torch.full((M, ldp), 9.0, device=dev)
+        v, dl, dls = torch.zeros(M, device=dev), torch.full((M, ldp), 9.0, device=dev), torch.full((M, ldp), 9.0, device=dev)
+        if fused:
+            L.d_head_lrelu(P.data_ptr(), ns, M * ldp, ldp, bias.data_ptr(), mask.data_ptr(), ldp, 0.2, H.data_ptr(), ldp,
+                           D.data_ptr(), ldp, w4.data_ptr(), b4.data_ptr(), M, K, rs.data_ptr(), v.data_ptr(), dl.data_ptr(),
+                           dls.data_ptr(), ldp, st)
+        else:
+            L.ep_lrelu_drop(P.data_ptr(), ns, M * ldp, ldp, M, K, bias.data_ptr(), mask.data_ptr(), ldp, 0.2, H.data_ptr(),
+                            ldp, D.data_ptr(), ldp, st)
+            L.d_head(H.data_ptr(), ldp, D.data_ptr(), ldp, w4.data_ptr(), b4.data_ptr(), M, K, rs.data_ptr(), v.data_ptr(),
+                     dl.data_ptr(), dls.data_ptr(), ldp, st)
+        torch.cuda.synchronize()
+        outs.append((H, D, v, dl, dls))
+    for a, b in zip(*outs):
+        assert torch.equal(a, b)
+    z = P[:, :, :K].double().sum(0).cpu() + bias.double().cpu()
+    h = torch.where(z > 0, z, 0.2 * z) * mask[:, :K].double().cpu()
+    ref = h @ w4.double().cpu() + b4.double().cpu()
+    assert (outs[1][2].double().cpu() - ref).abs().max().item() <= 1e-4 * (1 + ref.abs().max().item())

@@ -228,3 +228,42 @@ def test_grouped_trainer_cursor_handover():
     torch.cuda.synchronize()
     got = torch.cat(used)
     assert torch.equal(got, eng.data_X[perm])
+
+
+def test_grouped_mask_draw_equals_per_iteration_draws():
+    """GroupedTrainer draws the dropout keep-masks of its n critic passes and of its G-step in ONE launch at the head of
+    the group (wfd_rng_dropout_mask_slots): the same numbers each iteration would draw itself at its own Philox counter
+    (the counter advances once per optimizer step)."""
+    from wfd_gan_amd.engine import GroupedTrainer
+    from wfd_gan_amd._lib import lib
+    L = lib()
+    S, C, Z, B = 101, 6, 24, 16
+    X, y = O.synth_dataset(C, 30, S - 1, 10, 13, 122, seed=1)
+    dmin, dmax = X.min(0), X.max(0)
+    scale, min_ = O.scaler_params(dmin, dmax)
+    Xs = torch.from_numpy(X * scale + min_).float()
+    st = O.make_state(S, C, Z, dmin[0], dmax[0], seed=2, df_seed=3)
+    eng = _engine(S, C, Z, B, st, seed=11)
+    eng.attach_dataset(Xs, torch.from_numpy(y), shuffle_seed=5)
+    grp = GroupedTrainer(eng, graphs=False)
+    assert grp.merged_masks
+    assert not any(fn is L.rng_dropout_mask for p in grp.rest + [grp.gstep] for fn, _, _ in p.calls)
+    M64, inc = 2**64 - 1, eng._rng_inc()
+    stream = torch.cuda.current_stream().cuda_stream
+    for _ in range(2):
+        s0 = int(eng.iter_state[0])
+        grp.run_group()
+        torch.cuda.synchronize()
+        for k in range(3):
+            e = grp.slot(k)
+            want = torch.empty_like(e.buf["MKflat"])
+            L.rng_dropout_mask(want.data_ptr(), want.numel(), 0.2, (e.seed + eng.GOLD) & M64, 0, s0 + k * inc, stream)
+            torch.cuda.synchronize()
+            assert torch.equal(want, e.buf["MKflat"]), k
+        e = grp.slot(2)
+        want = torch.empty_like(e.buf["gMKflat"])
+        L.rng_dropout_mask(want.data_ptr(), want.numel(), 0.2, (e.seed + 4 * eng.GOLD) & M64, 0, s0 + 3 * inc, stream)
+        torch.cuda.synchronize()
+        assert torch.equal(want, e.buf["gMKflat"])
+        assert int(eng.iter_state[0]) == s0 + 4 * inc
+        assert set(e.buf["MKflat"].unique().tolist()) == {0.0, 1.25}

@@ -173,6 +173,35 @@ __global__ void d_head_kernel(const float* __restrict__ H3, int ldh, const float
     if (threadIdx.x == 0) v[m] = acc + b4[0];
 }
 
+// The last hidden layer's epilogue and the head in one launch (one dependent step less per critic pass): per row,
+// ep_lrelu_drop's math on the slabs of layer 3 (H3, D3 are still written: the weight gradients and the t-chain read them)
+// followed by d_head's on the values just computed.  Same operations in the same order as the two kernels.
+__global__ void d_head_lrelu_kernel(const float* __restrict__ P, int ns, long ss, int ldp,
+                                    const float* __restrict__ bias, const float* __restrict__ mask, int ldmask,
+                                    float slope, float* __restrict__ H3, int ldh, float* __restrict__ D3, int ldd,
+                                    const float* __restrict__ w4, const float* __restrict__ b4, int K,
+                                    const float* __restrict__ rowscale, float* __restrict__ v,
+                                    float* __restrict__ delta, float* __restrict__ delta_s, int ldo) {
+    __shared__ float red[16];
+    const int m = blockIdx.x;
+    float acc = 0.f;
+    for (int k = threadIdx.x; k < K; k += blockDim.x) {
+        const float zz = slab_sum(P, ns, ss, (long)m * ldp + k) + bias[k];
+        const float mk = mask[(long)m * ldmask + k];
+        const float lr = zz > 0.f ? zz : zz * slope;
+        const float h = lr * mk, d = zz > 0.f ? mk : mk * slope;
+        H3[(long)m * ldh + k] = h;
+        D3[(long)m * ldd + k] = d;
+        const float w = w4[k];
+        acc = __fmaf_rn(h, w, acc);
+        const float dl = w * d;
+        delta[(long)m * ldo + k] = dl;
+        if (delta_s) delta_s[(long)m * ldo + k] = dl * rowscale[m];
+    }
+    acc = block_sum(acc, red);
+    if (threadIdx.x == 0) v[m] = acc + b4[0];
+}
+
 // out = sumP * f(D) * colscale;  dmode: 0 no D, 1 multiply by D, 2 multiply by (D > 0), 3 ELU' from its output
 // (D > 0 ? 1 : D + 1).  Optional second copy out2 = out * rowscale[m].
 template <bool VEC>
@@ -921,6 +950,17 @@ int wfd_d_head(const float* H3, int ldh, const float* D3, int ldd, const float* 
     if (delta_s && !rowscale) return WFD_ERR_ARG;
     hipLaunchKernelGGL(d_head_kernel, dim3(M), dim3(256), 0, (hipStream_t)stream, H3, ldh, D3, ldd, w4, b4, K, rowscale,
                        v, delta, delta_s, ldo);
+    WFD_CHECK_LAUNCH();
+    return WFD_OK;
+}
+
+int wfd_d_head_lrelu(const float* P, int ns, long ss, int ldp, const float* bias, const float* mask, int ldmask,
+                     float slope, float* H3, int ldh, float* D3, int ldd, const float* w4, const float* b4, int M, int K,
+                     const float* rowscale, float* v, float* delta, float* delta_s, int ldo, void* stream) {
+    if (!P || !bias || !mask || !H3 || !D3 || !w4 || !b4 || !v || !delta || M <= 0 || K <= 0 || ns < 1) return WFD_ERR_ARG;
+    if (delta_s && !rowscale) return WFD_ERR_ARG;
+    hipLaunchKernelGGL(d_head_lrelu_kernel, dim3(M), dim3(256), 0, (hipStream_t)stream, P, ns, ss, ldp, bias, mask, ldmask,
+                       slope, H3, ldh, D3, ldd, w4, b4, K, rowscale, v, delta, delta_s, ldo);
     WFD_CHECK_LAUNCH();
     return WFD_OK;
 }

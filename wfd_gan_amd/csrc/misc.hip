@@ -36,6 +36,32 @@ __global__ void rng_dropout_mask_kernel(float* __restrict__ out, long n, float p
     }
 }
 
+// the same for up to 8 mask buffers in one launch (the masks of every iteration of a group of n_critic iterations):
+// blockIdx.y = slot; slot s draws with its own seed at counter state[0] + base[s]
+struct MaskSlots {
+    float* out[8];
+    long n[8];
+    unsigned long long seed[8];
+    unsigned long long base[8];
+};
+__global__ void rng_dropout_mask_slots_kernel(MaskSlots a, float p, const unsigned long long* __restrict__ state) {
+    const int s = blockIdx.y;
+    float* __restrict__ out = a.out[s];
+    const long n = a.n[s];
+    const unsigned long long seed = a.seed[s], offset = (state ? state[0] : 0ull) + a.base[s];
+    const float keep = 1.0f / (1.0f - p);
+    const long stride = (long)gridDim.x * blockDim.x;
+    for (long q = (long)blockIdx.x * blockDim.x + threadIdx.x; q * 4 < n; q += stride) {
+        const unsigned long long c = offset + (unsigned long long)q;
+        const uint4 r = philox4x32_10(make_uint4((uint32_t)c, (uint32_t)(c >> 32), 0x6d61736bu, 0u),
+                                      make_uint2((uint32_t)seed, (uint32_t)(seed >> 32)));
+        const float v[4] = {u01(r.x) >= p ? keep : 0.f, u01(r.y) >= p ? keep : 0.f, u01(r.z) >= p ? keep : 0.f,
+                            u01(r.w) >= p ? keep : 0.f};
+        for (int k = 0; k < 4; ++k)
+            if (q * 4 + k < n) out[q * 4 + k] = v[k];
+    }
+}
+
 // standard normal into rows of a strided matrix: out[m][0..Z) (Box-Muller on Philox uniforms)
 __global__ void rng_normal_rows_kernel(float* __restrict__ out, int ld, int M, int Z, unsigned long long seed,
                                        const unsigned long long* __restrict__ state, unsigned long long base) {
@@ -401,6 +427,28 @@ __global__ __launch_bounds__(256) void extract_bursts_kernel(const double* __res
 }  // namespace
 
 extern "C" {
+
+int wfd_rng_dropout_mask_slots(const unsigned long long* slots, int nslots, float p, const unsigned long long* state,
+                               void* stream) {
+    if (!slots || nslots < 1 || nslots > 8 || p < 0.f || p >= 1.f) return WFD_ERR_ARG;
+    MaskSlots a{};
+    long nmax = 0;
+    for (int s = 0; s < nslots; ++s) {
+        a.out[s] = reinterpret_cast<float*>(slots[4 * s]);
+        a.n[s] = (long)slots[4 * s + 1];
+        a.seed[s] = slots[4 * s + 2];
+        a.base[s] = slots[4 * s + 3];
+        if (!a.out[s] || a.n[s] <= 0) return WFD_ERR_ARG;
+        if (a.n[s] > nmax) nmax = a.n[s];
+    }
+    long blocks = (nmax / 4 + 255) / 256;
+    if (blocks > 1024) blocks = 1024;
+    if (blocks < 1) blocks = 1;
+    hipLaunchKernelGGL(rng_dropout_mask_slots_kernel, dim3((unsigned)blocks, nslots), dim3(256), 0, (hipStream_t)stream, a, p,
+                       state);
+    WFD_CHECK_LAUNCH();
+    return WFD_OK;
+}
 
 int wfd_rng_dropout_mask(float* out, long n, float p, unsigned long long seed, const unsigned long long* state,
                          unsigned long long base, void* stream) {

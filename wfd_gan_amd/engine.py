@@ -12,6 +12,7 @@ Real and fake rows are stacked (2B rows) so every weight matrix is streamed once
 """
 from __future__ import annotations
 
+import ctypes
 import math
 from typing import Dict, List, Optional, Sequence, Tuple
 
@@ -397,9 +398,10 @@ class TrainEngine:
         s = p.gemm(NT, H1, 2048, D["model.3.weight"], 2048, M, 1024, 2048)
         p.lrelu_drop(s, D["model.3.bias"], mk[1], 1024, H2, 1024, D2, 1024)
         s = p.gemm(NT, H2, 1024, D["model.6.weight"], 1024, M, 512, 1024)
-        p.lrelu_drop(s, D["model.6.bias"], mk[2], 512, H3, 512, D3, 512)
-        p.add(self.L.d_head, ptr(H3), 512, ptr(D3), 512, ptr(D["model.9.weight"]), ptr(D["model.9.bias"]), M, 512,
-              ptr(rowscale), ptr(V), ptr(DL3), ptr(DL3s), 512)
+        # layer-3 epilogue + head (nn.Linear(512, 1)) + first step of the input-gradient chain in one launch
+        p.add(self.L.d_head_lrelu, s.ptr, s.ns, s.ss, s.ldp, ptr(D["model.6.bias"]), ptr(mk[2]), 512, 0.2, ptr(H3), 512,
+              ptr(D3), 512, ptr(D["model.9.weight"]), ptr(D["model.9.bias"]), M, 512, ptr(rowscale), ptr(V), ptr(DL3),
+              ptr(DL3s), 512)
 
     def _critic_chain(self, p: Plan, M: int, DL3, DL2, DL2s, DL1, DL1s, D2, D1, rowscale) -> Slabs:
         """d validity / d traces in closed form; returns the slabs of g = (delta_1 W_1)[:, :S]."""
@@ -415,7 +417,7 @@ class TrainEngine:
     def _rng_inc(self) -> int:
         return max((self.B * self.Z + 3) // 4, (self.buf["MKflat"].numel() + 3) // 4)
 
-    def _build_d_plan(self, fast: bool = False, part: str = "all") -> Plan:
+    def _build_d_plan(self, fast: bool = False, part: str = "all", draw_masks: bool = True) -> Plan:
         """fast: the batch, z and the dropout masks are produced on device from the resident dataset / Philox and
         the step ends by advancing the device-resident iteration state (graph-replayable); otherwise the caller
         supplies them (parity mode).
@@ -428,8 +430,10 @@ class TrainEngine:
             if part == "rest_draw":
                 # the head ran stacked with other iterations' heads (GroupedTrainer) and drew only z: the dropout masks
                 # (and the WGAN-GP interpolates) of this iteration are produced here
+                # (draw_masks = False: the group's head already drew them, GroupedTrainer._build_head)
                 t = b["MKflat"]
-                p.add(self.L.rng_dropout_mask, ptr(t), t.numel(), 0.2, (self.seed + self.GOLD) & (2**64 - 1), st, 0)
+                if draw_masks:
+                    p.add(self.L.rng_dropout_mask, ptr(t), t.numel(), 0.2, (self.seed + self.GOLD) & (2**64 - 1), st, 0)
                 if self.penalty == "gp":
                     p.add(self.L.rng_uniform, ptr(b["GPA"]), B, (self.seed + 11 * self.GOLD) & (2**64 - 1), st, 0)
                     p.add(self.L.interpolate_rows, ptr(self.real_rows), ptr(self.fake_rows), ptr(b["GPA"]),
@@ -627,11 +631,11 @@ class TrainEngine:
         ghead = self.buf["ghead"]
         p.host(lambda: self.comm.all_reduce_sum_(ghead))
 
-    def _build_g_plan(self, fast: bool = False) -> Plan:
+    def _build_g_plan(self, fast: bool = False, draw_masks: bool = True) -> Plan:
         B, S, C, Z, b, G = self.B, self.S, self.C, self.Z, self.buf, self.Gp
         p = Plan(b["ws"], b["ws2"], self.overlap, self.gemm_mode)
         st = self.iter_state.data_ptr()
-        if fast:
+        if fast and draw_masks:
             t = b["gMKflat"]
             p.add(self.L.rng_dropout_mask, ptr(t), t.numel(), 0.2, (self.seed + 4 * self.GOLD) & (2**64 - 1), st, 0)
         # The generator parameters and z are unchanged since the D-step's forward, so the second
@@ -1099,9 +1103,10 @@ class GroupedTrainer:
                 setattr(e, name, getattr(eng, name))
         eng.gf_state.zero_()
         self.ws = torch.empty(max(16 * n * eng.B * 2048, 1 << 20), dtype=torch.float32, device=dev)
+        self.merged_masks = n + 1 <= 8          # one launch draws the dropout masks of the whole group (8 buffers at most)
         self.head = self._build_head()
-        self.rest = [e._build_d_plan(fast=True, part="rest_draw") for e in self.e]
-        self.gstep = self.e[n - 1]._build_g_plan(fast=True)
+        self.rest = [e._build_d_plan(fast=True, part="rest_draw", draw_masks=not self.merged_masks) for e in self.e]
+        self.gstep = self.e[n - 1]._build_g_plan(fast=True, draw_masks=not self.merged_masks)
         self.group = Plan(self.ws, gemm_mode=eng.gemm_mode)
         self.group.extend(self.head)
         for r in self.rest:
@@ -1118,6 +1123,19 @@ class GroupedTrainer:
         B, S, C, Z, G, st = eng.B, eng.S, eng.C, eng.Z, eng.Gp.p, self.stacked
         M = n * B
         p = Plan(self.ws, gemm_mode=eng.gemm_mode)
+        # the dropout keep-masks of the group's n critic passes and of its G-step in one launch: the same numbers the
+        # iterations would draw themselves (iteration k starts k optimizer steps, i.e. k counter increments, after this
+        # point; the G-step after all n)
+        if self.merged_masks:
+            inc, M64 = eng._rng_inc(), 2**64 - 1
+            slots = []
+            for k, e in enumerate(self.e):
+                t = e.buf["MKflat"]
+                slots += [t.data_ptr(), t.numel(), (e.seed + eng.GOLD) & M64, k * inc]
+            ge = self.e[n - 1]
+            slots += [ge.buf["gMKflat"].data_ptr(), ge.buf["gMKflat"].numel(), (ge.seed + 4 * eng.GOLD) & M64, n * inc]
+            self._mask_slots = (ctypes.c_ulonglong * len(slots))(*slots)
+            p.add(L.rng_dropout_mask_slots, self._mask_slots, len(slots) // 4, 0.2, eng.iter_state.data_ptr())
         state = eng.gf_state.data_ptr()
         xc = st["XC"]                                   # [n][2*Mslot][ldx]
         slot_stride = xc.stride(0)
