@@ -638,12 +638,16 @@ int wfd_set_gemm_mode(int mode) {
 
 int wfd_get_gemm_mode(void) { return g_gemm_mode; }
 
-// Number of K splits the library would pick for an (M,N,K) product: enough workgroups to cover the 256 CUs about
+// Number of K splits the library would pick for an (M,N,K) product: enough workgroups to cover the 256 CUs once or
 // twice, never thinner than 2 k-tiles per split.  The caller sizes the slab workspace with it.
 int wfd_gemm_pick_splits(int M, int N, int K) {
     const int tiles = cdiv(M, BM) * (N <= 32 ? cdiv(N, 32) : cdiv(N, BN));
     const int ktiles = cdiv(K, BK);
-    int s = 512 / (tiles > 0 ? tiles : 1);
+    // two workgroups per CU when the tiles alone cover a good part of the chip, one per CU below that: every extra split
+    // is one more slab for the consumer to read back, and with few tiles the slabs outweigh the second workgroup
+    // (measured on the config-2 step: 32 tiles x 8 splits beats x 16 by 2.5 % of the whole step, 64 tiles x 8 beats x 4)
+    const int target = tiles >= 40 ? 512 : 256;
+    int s = target / (tiles > 0 ? tiles : 1);
     if (s < 1) s = 1;
     if (s > 16) s = 16;
     while (s > 1 && ktiles / s < 2) --s;
