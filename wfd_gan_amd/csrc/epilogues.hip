@@ -1032,7 +1032,7 @@ int wfd_bn_train_relu(const float* P, int ns, long ss, int ldp, int M, int N, co
                       float* invstd, float* rmean, float* rvar, float momentum, int nupd, void* stream) {
     if (!P || !gamma || !beta || !XH || !H || !mean || !m2 || !invstd || M < 2) return WFD_ERR_ARG;
     if (M <= RG * 8) {
-        constexpr int CTS = 8;
+        constexpr int CTS = 32;          // a block reads whole 128-byte lines of its rows (8 columns: 4x the bytes, 1 % of the B=64 step)
         if (M <= RG * 4)
             hipLaunchKernelGGL((bn_train_relu_small_kernel<CTS, 4>), dim3(cdiv(N, CTS)), dim3(CTS, RG), 0,
                                (hipStream_t)stream, P, ns, ss, ldp, M, N, bias, eps, gamma, beta, XH, H, ldo, mean, m2,
@@ -1091,7 +1091,7 @@ int wfd_bn_train_relu_grouped(const float* P, int ns, long ss, int ldp, int M, i
                               float* m2, float* invstd, float* rmean, float* rvar, float momentum, void* stream) {
     if (!P || !gamma || !beta || !XH || !H || !mean || !m2 || !invstd || M < 2 || groups < 1 || M > RG * 8)
         return WFD_ERR_ARG;
-    constexpr int CTS = 8;
+    constexpr int CTS = 32;          // a block reads whole 128-byte lines of its rows (8 columns: 4x the bytes, 1 % of the B=64 step)
     hipStream_t st = (hipStream_t)stream;
     if (M <= RG * 4)
         hipLaunchKernelGGL((bn_train_relu_small_kernel<CTS, 4>), dim3(cdiv(N, CTS), groups), dim3(CTS, RG), 0, st, P, ns, ss,
@@ -1116,7 +1116,7 @@ int wfd_bn_bwd(const float* P, int ns, long ss, int ldp, int M, int N, const flo
     if (!P || !H || !XH || !gamma || !invstd || !sums) return WFD_ERR_ARG;
     if (!DZ || ((phase & 2) && (!dgamma || !dbeta || !dbias))) return WFD_ERR_ARG;
     if (phase == 3 && M <= RG * 8) {
-        constexpr int CTS = 8;
+        constexpr int CTS = 32;          // a block reads whole 128-byte lines of its rows (8 columns: 4x the bytes, 1 % of the B=64 step)
         if (M <= RG * 4)
             hipLaunchKernelGGL((bn_bwd_small_kernel<CTS, 4>), dim3(cdiv(N, CTS)), dim3(CTS, RG), 0, (hipStream_t)stream, P,
                                ns, ss, ldp, M, N, H, XH, ldh, gamma, invstd, count, sums, DZ, lddz, dgamma, dbeta, dbias);
