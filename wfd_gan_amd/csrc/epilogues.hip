@@ -905,9 +905,14 @@ __global__ void g_head_kernel(const float* __restrict__ fv, int B, float invB, f
 
 // ---- internal launchers (used by step.hip) and their extern "C" faces -----------------------------------------
 static inline dim3 col_grid(int N, int M, int bx = 256) { return dim3(cdiv(N, bx), M < 64 ? M : 64); }
+// threads per block of the flat element-wise epilogues: single-wave blocks while the whole tensor is a few hundred waves
+// (batch-64 layers: the blocks then spread over all CUs instead of filling a quarter of them; +0.6 % on the step),
+// 256 threads once there are enough of those to cover the chip
+static inline int ep_block(int M, int N) { return (long)M * ((N + 3) / 4) <= 131072 ? 64 : 256; }
 static inline unsigned flat_grid(int M, int N) {
     const long t = (long)M * ((N + 3) / 4);
-    long b = (t + 255) / 256;
+    const int bs = ep_block(M, N);
+    long b = (t + bs - 1) / bs;
     if (b > 8192) b = 8192;
     return (unsigned)(b < 1 ? 1 : b);
 }
@@ -920,10 +925,10 @@ int wfd_ep_affine_act(const float* P, int ns, long ss, int ldp, int M, int N, co
     if (!P || !out || M <= 0 || N <= 0) return WFD_ERR_ARG;
     const bool vec = al16(P) && al16(out) && !(ldp & 3) && !(ldo & 3) && !(ss & 3) && !(N & 3);
     if (vec)
-        hipLaunchKernelGGL(ep_affine_act_kernel<true>, dim3(flat_grid(M, N)), dim3(256), 0, (hipStream_t)stream, P, ns,
+        hipLaunchKernelGGL(ep_affine_act_kernel<true>, dim3(flat_grid(M, N)), dim3(ep_block(M, N)), 0, (hipStream_t)stream, P, ns,
                            ss, ldp, M, N, scale, shift, act, out, ldo);
     else
-        hipLaunchKernelGGL(ep_affine_act_kernel<false>, dim3(flat_grid(M, N)), dim3(256), 0, (hipStream_t)stream, P, ns,
+        hipLaunchKernelGGL(ep_affine_act_kernel<false>, dim3(flat_grid(M, N)), dim3(ep_block(M, N)), 0, (hipStream_t)stream, P, ns,
                            ss, ldp, M, N, scale, shift, act, out, ldo);
     WFD_CHECK_LAUNCH();
     return WFD_OK;
@@ -935,10 +940,10 @@ int wfd_ep_lrelu_drop(const float* P, int ns, long ss, int ldp, int M, int N, co
     const bool vec = al16(P) && al16(mask) && al16(H) && al16(D) && !(ldp & 3) && !(ldmask & 3) && !(ldh & 3) &&
                      !(ldd & 3) && !(ss & 3) && !(N & 3);
     if (vec)
-        hipLaunchKernelGGL(ep_lrelu_drop_kernel<true>, dim3(flat_grid(M, N)), dim3(256), 0, (hipStream_t)stream, P, ns,
+        hipLaunchKernelGGL(ep_lrelu_drop_kernel<true>, dim3(flat_grid(M, N)), dim3(ep_block(M, N)), 0, (hipStream_t)stream, P, ns,
                            ss, ldp, M, N, bias, mask, ldmask, slope, H, ldh, D, ldd);
     else
-        hipLaunchKernelGGL(ep_lrelu_drop_kernel<false>, dim3(flat_grid(M, N)), dim3(256), 0, (hipStream_t)stream, P, ns,
+        hipLaunchKernelGGL(ep_lrelu_drop_kernel<false>, dim3(flat_grid(M, N)), dim3(ep_block(M, N)), 0, (hipStream_t)stream, P, ns,
                            ss, ldp, M, N, bias, mask, ldmask, slope, H, ldh, D, ldd);
     WFD_CHECK_LAUNCH();
     return WFD_OK;
@@ -971,10 +976,10 @@ int wfd_ep_mul(const float* P, int ns, long ss, int ldp, int M, int N, const flo
     const bool vec = al16(P) && al16(D) && al16(out) && al16(out2) && !(ldp & 3) && !(ldd & 3) && !(ldo & 3) &&
                      !(ss & 3) && !(N & 3);
     if (vec)
-        hipLaunchKernelGGL(ep_mul_kernel<true>, dim3(flat_grid(M, N)), dim3(256), 0, (hipStream_t)stream, P, ns, ss, ldp,
+        hipLaunchKernelGGL(ep_mul_kernel<true>, dim3(flat_grid(M, N)), dim3(ep_block(M, N)), 0, (hipStream_t)stream, P, ns, ss, ldp,
                            M, N, D, ldd, dmode, colscale, rowscale, out, out2, ldo);
     else
-        hipLaunchKernelGGL(ep_mul_kernel<false>, dim3(flat_grid(M, N)), dim3(256), 0, (hipStream_t)stream, P, ns, ss,
+        hipLaunchKernelGGL(ep_mul_kernel<false>, dim3(flat_grid(M, N)), dim3(ep_block(M, N)), 0, (hipStream_t)stream, P, ns, ss,
                            ldp, M, N, D, ldd, dmode, colscale, rowscale, out, out2, ldo);
     WFD_CHECK_LAUNCH();
     return WFD_OK;
