@@ -916,6 +916,9 @@ static inline unsigned flat_grid(int M, int N) {
     if (b > 8192) b = 8192;
     return (unsigned)(b < 1 ? 1 : b);
 }
+// one workgroup per row in the head kernels: one column per thread at the reference's width (512), so the row is a single
+// round of loads (same rule in wfd_d_head and wfd_d_head_lrelu: their sums stay bit-identical)
+static inline int head_block(int K) { return K >= 512 ? 512 : 256; }
 static inline bool al16(const void* p) { return p == nullptr || (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
 
 extern "C" {
@@ -953,7 +956,7 @@ int wfd_d_head(const float* H3, int ldh, const float* D3, int ldd, const float* 
                const float* rowscale, float* v, float* delta, float* delta_s, int ldo, void* stream) {
     if (!H3 || !D3 || !w4 || !b4 || !v || !delta) return WFD_ERR_ARG;
     if (delta_s && !rowscale) return WFD_ERR_ARG;
-    hipLaunchKernelGGL(d_head_kernel, dim3(M), dim3(256), 0, (hipStream_t)stream, H3, ldh, D3, ldd, w4, b4, K, rowscale,
+    hipLaunchKernelGGL(d_head_kernel, dim3(M), dim3(head_block(K)), 0, (hipStream_t)stream, H3, ldh, D3, ldd, w4, b4, K, rowscale,
                        v, delta, delta_s, ldo);
     WFD_CHECK_LAUNCH();
     return WFD_OK;
@@ -964,7 +967,7 @@ int wfd_d_head_lrelu(const float* P, int ns, long ss, int ldp, const float* bias
                      const float* rowscale, float* v, float* delta, float* delta_s, int ldo, void* stream) {
     if (!P || !bias || !mask || !H3 || !D3 || !w4 || !b4 || !v || !delta || M <= 0 || K <= 0 || ns < 1) return WFD_ERR_ARG;
     if (delta_s && !rowscale) return WFD_ERR_ARG;
-    hipLaunchKernelGGL(d_head_lrelu_kernel, dim3(M), dim3(256), 0, (hipStream_t)stream, P, ns, ss, ldp, bias, mask, ldmask,
+    hipLaunchKernelGGL(d_head_lrelu_kernel, dim3(M), dim3(head_block(K)), 0, (hipStream_t)stream, P, ns, ss, ldp, bias, mask, ldmask,
                        slope, H3, ldh, D3, ldd, w4, b4, K, rowscale, v, delta, delta_s, ldo);
     WFD_CHECK_LAUNCH();
     return WFD_OK;
@@ -988,7 +991,7 @@ int wfd_ep_mul(const float* P, int ns, long ss, int ldp, int M, int N, const flo
 int wfd_ep_penalty_row(const float* P, int ns, long ss, int ldp, int M, int S, int mode, float invB, float lambda,
                        const float* rowflag, float* nsq, float* pen, float* GH, int ldg, void* stream) {
     if (!P || !nsq || !pen || !GH || S <= 0 || (size_t)S * 4 > 60000) return WFD_ERR_ARG;
-    hipLaunchKernelGGL(ep_penalty_row_kernel, dim3(M), dim3(512), (size_t)S * sizeof(float), (hipStream_t)stream, P, ns,
+    hipLaunchKernelGGL(ep_penalty_row_kernel, dim3(M), dim3(S >= 1024 ? 1024 : 512), (size_t)S * sizeof(float), (hipStream_t)stream, P, ns,
                        ss, ldp, S, mode, invB, lambda, rowflag, nsq, pen, GH, ldg);
     WFD_CHECK_LAUNCH();
     return WFD_OK;
