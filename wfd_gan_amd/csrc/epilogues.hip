@@ -1018,7 +1018,7 @@ int wfd_rmsprop(float* p, const float* g, float* sq, long n, float lr, float alp
     if (!p || !g || !sq || n <= 0) return WFD_ERR_ARG;
     if ((((uintptr_t)p | (uintptr_t)g | (uintptr_t)sq) & 15) != 0) return WFD_ERR_ARG;
     long blocks = (n / 4 + 255) / 256;
-    if (blocks > 2048) blocks = 2048;
+    if (blocks > 8192) blocks = 8192;          // one float4 per thread up to 8.4 M parameters (both networks here)
     if (blocks < 1) blocks = 1;
     hipLaunchKernelGGL(rmsprop_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, p, g, sq, n, lr, alpha,
                        eps, gscale, state, inc0, inc1);
