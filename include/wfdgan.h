@@ -328,6 +328,15 @@ int wfd_bn_tall_bwd(const float* dA, const float* Z, int M, int N, int rows_per_
                     void* stream);
 /* out[n] = sum_m X[m][n] over a tall matrix (conv bias gradients); part: ceil(M / rows_per_chunk) * N floats */
 int wfd_colsum_tall(const float* X, int ld, int M, int N, int rows_per_chunk, float* part, float* out, void* stream);
+/* wfd_colsum_tall for callers that cannot allocate or pass a workspace (code under HIP-graph capture, tight serving
+ * loops, harnesses that forbid hipMalloc).  NO COUNTERPART IN THE REFERENCE.  The chunk partials live in a static device
+ * array inside the library (wfd_static_scratch_floats() floats = 4 MiB, resident on every GPU the library runs on until the
+ * process ends); the call allocates nothing.  Returns 3 when ceil(M / rows_per_chunk) * N exceeds that size (use
+ * wfd_colsum_tall with a workspace then).  Same kernels, same summation order, bit-identical results.  All calls on one
+ * GPU share the array: calls that overlap on one GPU (different streams) race -- serialise them.  The first call on a
+ * device looks the array's address up (hipGetSymbolAddress): make it outside stream capture. */
+int wfd_colsum_tall_static(const float* X, int ld, int M, int N, int rows_per_chunk, float* out, void* stream);
+int wfd_static_scratch_floats(void);
 /* weight gradient of the first conv (Cin = 1): dW[co][t] = sum_{b,l} dZ[b][l][co] * x[b][l+t-3], x[b][l] = X[b*ldx+xoff+l];
  * part: ceil(L / 128) * Bn * Cout * 8 floats */
 int wfd_conv1_wgrad(const float* dZ, const float* X, int ldx, int xoff, int Bn, int L, int Cout, float* part, float* dW,

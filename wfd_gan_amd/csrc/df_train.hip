@@ -7,6 +7,7 @@
 // Tall reductions are two-stage and deterministic: a grid of row chunks writes per-chunk partials, a second tiny
 // kernel combines them in chunk order (Chan's pairwise update for mean / M2).
 #include "common.h"
+#include <mutex>
 
 namespace {
 
@@ -286,6 +287,30 @@ inline unsigned flat_blocks(long n) {
 
 }  // namespace
 
+// ---- wfd_colsum_tall for callers that cannot allocate (HIP-graph capture, serving loops) -------------------------------
+// The chunk partials live in a file-scope device array instead of a caller workspace.  `scratch` below is the HOST-side
+// stand-in of that array: only hipGetSymbolAddress turns it into this device's address, once per device (every GPU holds
+// its own copy at its own address), and from then on host code uses the looked-up pointer, never the array's name.
+constexpr long SCRATCH_FLOATS = 1L << 20;          // 1 Mi floats = 4 MiB on every GPU the library runs on, held until process exit
+static __device__ __align__(256) float scratch[SCRATCH_FLOATS];
+constexpr int SCRATCH_MAX_DEVICES = 64;
+static float* g_scratch_ptr[SCRATCH_MAX_DEVICES] = {};
+static std::mutex g_scratch_mutex;
+
+// device pointer of the CURRENT device's copy of `scratch` (looked up on the first call on that device)
+static int scratch_of_current_device(float** out) {
+    int dev = -1;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= SCRATCH_MAX_DEVICES) return WFD_ERR_LAUNCH;
+    std::lock_guard<std::mutex> lock(g_scratch_mutex);
+    if (!g_scratch_ptr[dev]) {
+        float* p = nullptr;
+        if (hipGetSymbolAddress((void**)&p, HIP_SYMBOL(scratch)) != hipSuccess || !p) return WFD_ERR_LAUNCH;
+        g_scratch_ptr[dev] = p;
+    }
+    *out = g_scratch_ptr[dev];
+    return WFD_OK;
+}
+
 extern "C" {
 
 int wfd_bn_tall_stats(const float* Z, int ldz, int M, int N, int rows_per_chunk, float* part, float eps, float momentum,
@@ -336,6 +361,26 @@ int wfd_bn_tall_bwd(const float* dA, const float* Z, int M, int N, int rows_per_
 
 int wfd_colsum_tall(const float* X, int ld, int M, int N, int rows_per_chunk, float* part, float* out, void* stream) {
     if (!X || !part || !out || M <= 0 || N <= 0 || rows_per_chunk <= 0) return WFD_ERR_ARG;
+    const int nchunk = cdiv(M, rows_per_chunk);
+    hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL(colsum_tall_partial_kernel, dim3(cdiv(N, TC), nchunk), dim3(TC, TR), 0, st, X, ld, M, N,
+                       rows_per_chunk, part);
+    WFD_CHECK_LAUNCH();
+    hipLaunchKernelGGL(sum_partials_kernel, dim3(cdiv(N, TC)), dim3(TC, CG), 0, st, part, nchunk, N, out, (float*)nullptr, 0);
+    WFD_CHECK_LAUNCH();
+    return WFD_OK;
+}
+
+int wfd_static_scratch_floats(void) { return (int)SCRATCH_FLOATS; }
+
+int wfd_colsum_tall_static(const float* X, int ld, int M, int N, int rows_per_chunk, float* out, void* stream) {
+    if (!X || !out || M <= 0 || N <= 0 || rows_per_chunk <= 0 || ld < N) return WFD_ERR_ARG;
+    const long need = (long)cdiv(M, rows_per_chunk) * N;
+    if (need > SCRATCH_FLOATS) return WFD_ERR_WORKSPACE;          // beyond the static array: use wfd_colsum_tall
+    float* part = nullptr;
+    const int rc = scratch_of_current_device(&part);
+    if (rc != WFD_OK) return rc;
+    // every partial the second kernel reads is written by the first one: nothing has to start at zero
     const int nchunk = cdiv(M, rows_per_chunk);
     hipStream_t st = (hipStream_t)stream;
     hipLaunchKernelGGL(colsum_tall_partial_kernel, dim3(cdiv(N, TC), nchunk), dim3(TC, TR), 0, st, X, ld, M, N,
