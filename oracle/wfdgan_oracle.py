@@ -313,8 +313,10 @@ def draw_dropout_masks(batch: int, dtype=torch.float32) -> List[torch.Tensor]:
 
 def iteration(st: OracleState, traces: torch.Tensor, labels: torch.Tensor, z: torch.Tensor, do_g: bool,
               masks_real=None, masks_fake=None, masks_g=None, gp_alpha: Optional[torch.Tensor] = None,
-              masks_gp=None, keep: bool = False) -> Dict[str, object]:
+              masks_gp=None, keep: bool = False, after_d_step=None) -> Dict[str, object]:
     """One pass of the loop body src/mlp_df_wgan_train.py:182-275.
+    ``after_d_step(st)`` (tests only) is called right after optimizer_D.step(): a parity test that evaluates the G-step on
+    the device's own post-step critic parameters loads them into ``st.D`` there.
 
     traces (B,S) already scaled, labels (B,) int64, z (B,Z).  Masks None -> drawn from the global torch
     generator in the reference's order.  Returns python floats / tensors of everything the parity tests look
@@ -358,6 +360,8 @@ def iteration(st: OracleState, traces: torch.Tensor, labels: torch.Tensor, z: to
     if keep:
         out["d_grads"] = [p.grad.detach().clone() for p in st.d_params()]
     st.opt_D.step()                                                           # :230
+    if after_d_step is not None:
+        after_d_step(st)
 
     st.opt_G.zero_grad()                                                      # :232
     out["did_g"] = bool(do_g)

@@ -141,12 +141,15 @@ def slices(t, n=16):
 
 
 def make_case(ref_model, name, seq_len, class_dim, latent_dim, batch, n_iter, seed, data_seed, lr=2e-4,
-              alpha=0.02, n_critic=3, full_rows=4):
-    """One fixture: n_iter iterations from seeded init, on seeded synthetic data."""
+              alpha=0.02, n_critic=3, full_rows=4, store_inputs=True):
+    """One fixture: n_iter iterations from seeded init, on seeded synthetic data.
+    store_inputs=False (the large config-4 shapes): the batch and z are NOT stored; the fixture keeps the recipe
+    (dataset seed / arguments, row indices, z seed) and checksums, and tests/util.iter_inputs re-derives them."""
     print(f"[case {name}] S={seq_len} C={class_dim} Z={latent_dim} B={batch} iters={n_iter}")
     L = seq_len - 1
-    X, y = O.synth_dataset(class_dim, max(2, (batch * n_iter) // class_dim + 1), L, max(2, L // 20),
-                           75 if L > 600 else 13, 179 if L > 600 else 122, seed=data_seed)
+    synth_args = dict(n_cls=class_dim, n_inst=max(2, (batch * n_iter) // class_dim + 1), L=L, n_lo=max(2, L // 20),
+                      max_out=75 if L > 600 else 13, max_in=179 if L > 600 else 122, seed=data_seed)
+    X, y = O.synth_dataset(**synth_args)
     dmin, dmax = X.min(0), X.max(0)
     scale, min_ = O.scaler_params(dmin, dmax)
     Xs = X * scale + min_
@@ -176,7 +179,7 @@ def make_case(ref_model, name, seq_len, class_dim, latent_dim, batch, n_iter, se
                                    batch=batch, n_iter=n_iter, seed=seed, df_seed=seed + 100,
                                    df_bn_seed=seed + 101, lr=lr, alpha=alpha, n_critic=n_critic,
                                    scaler_min=float(smin), scaler_max=float(smax),
-                                   torch=torch.__version__)),
+                                   torch=torch.__version__, synth_args=synth_args, z_seed=seed + 7)),
               g_init_checksum=checksum(st.G), d_init_checksum=checksum(st.D), df_checksum=checksum(st.DF))
     zrng = np.random.RandomState(seed + 7)
     torch.manual_seed(seed + 13)                     # dropout stream for the run
@@ -218,9 +221,14 @@ def make_case(ref_model, name, seq_len, class_dim, latent_dim, batch, n_iter, se
               + (f" g={r['g_loss']:.6f} f={r['f_loss']:.6f} nsel={r['n_sel']}" if do_g else ""))
 
         p = f"it{it}_"
-        fx[p + "traces"] = Xs[idx].astype(np.float32)
-        fx[p + "labels"] = y[idx]
-        fx[p + "z"] = z.numpy()
+        if store_inputs:
+            fx[p + "traces"] = Xs[idx].astype(np.float32)
+            fx[p + "labels"] = y[idx]
+            fx[p + "z"] = z.numpy()
+        else:
+            fx[p + "rows"] = idx.astype(np.int64)
+            fx[p + "traces_sum"] = float(Xs[idx].astype(np.float32).astype(np.float64).sum())
+            fx[p + "z_sum"] = float(z.double().abs().sum())
         for nm, ms in (("mreal", m_real), ("mfake", m_fake), ("mg", m_g)):
             if ms is not None:
                 for li, pk in enumerate(pack_masks(ms)):
@@ -657,6 +665,12 @@ def main():
     if not args.only or args.only == "cfg2":
         make_case(ref_model, "cfg2", seq_len=1401, class_dim=100, latent_dim=500, batch=64, n_iter=2, seed=21,
                   data_seed=0)
+    # BASELINE config 4 shapes (large batch, L = 2500 / 5000; DF FC-in 256 / 512): inputs re-derived from seeds
+    if not args.only or args.only == "cfg4":
+        make_case(ref_model, "cfg4a", seq_len=2501, class_dim=100, latent_dim=500, batch=256, n_iter=2, seed=61,
+                  data_seed=2, store_inputs=False)
+        make_case(ref_model, "cfg4b", seq_len=5001, class_dim=20, latent_dim=500, batch=128, n_iter=1, seed=62,
+                  data_seed=3, store_inputs=False)
     if not args.only or args.only == "sampler":
         make_sampler_case(ref_model, "cfg2", 1401, 100, 500, 100, seed=31)
         make_sampler_case(ref_model, "tiny", 41, 5, 16, 50, seed=32)

@@ -7,10 +7,10 @@ import pytest
 import torch
 
 from oracle import wfdgan_oracle as O
-from tests.util import GOLDEN, load_iter_fixture, rebuild_state, unpack_masks
+from tests.util import GOLDEN, iter_inputs, load_iter_fixture, rebuild_state, unpack_masks
 
 
-@pytest.mark.parametrize("name", ["tiny", "cfg1"])
+@pytest.mark.parametrize("name", ["tiny", "cfg1", "cfg4b"])
 def test_oracle_iteration_reproduces_reference_fixture(name):
     torch.set_num_threads(8)
     fx, meta = load_iter_fixture(name)
@@ -19,8 +19,9 @@ def test_oracle_iteration_reproduces_reference_fixture(name):
     for it in range(meta["n_iter"]):
         p = f"it{it}_"
         do_g = it % meta["n_critic"] == 0
-        r = O.iteration(st, torch.from_numpy(fx[p + "traces"]).double(), torch.from_numpy(fx[p + "labels"]),
-                        torch.from_numpy(fx[p + "z"]), do_g, unpack_masks(fx, p + "mreal", B),
+        traces, labels, z = iter_inputs(fx, meta, it)
+        r = O.iteration(st, torch.from_numpy(traces).double(), torch.from_numpy(labels),
+                        torch.from_numpy(z), do_g, unpack_masks(fx, p + "mreal", B),
                         unpack_masks(fx, p + "mfake", B), unpack_masks(fx, p + "mg", B), keep=True)
         sc = fx[p + "scalars"]
         # same machine class, same torch build: the fixture was asserted bit-exact at generation time; allow
@@ -34,6 +35,33 @@ def test_oracle_iteration_reproduces_reference_fixture(name):
             assert abs(r["g_loss"] - gs[0]) <= 2e-5 * abs(gs[0]) + 1e-7
             assert abs(r["f_loss"] - gs[1]) <= 2e-5 * abs(gs[1]) + 1e-7
             assert r["n_sel"] == int(gs[3])
+
+
+def test_oracle_training_run_reproduces_reference_script():
+    """PIN C without a manual make_golden.py run: tests/golden/script_run.npz holds what the UNMODIFIED reference trainer
+    (src/mlp_df_wgan_train.py run end-to-end by runpy, seeded) wrote -- loss.npz, the row sums of epoch_1.npz's recon_x,
+    its labels, checksums of the two checkpoints.  oracle.train_loop.run_training under the same seeds must give them
+    again (last-ulp drift across host CPUs allowed)."""
+    from oracle import train_loop as TL
+    from tests.util import checksum
+    torch.set_num_threads(8)
+    fx = np.load(os.path.join(GOLDEN, "script_run.npz"))
+    meta = json.loads(str(fx["meta"]))
+    X, y = O.synth_dataset(meta["n_cls"], meta["n_inst"], meta["L"], 20, 13, 122, seed=0)
+    torch.manual_seed(meta["df_seed"])
+    df_sd = O.make_df_state(meta["L"], meta["n_cls"])
+    torch.manual_seed(meta["torch_seed"])
+    np.random.seed(meta["np_seed"])
+    mine = TL.run_training(X.copy(), y.copy(), df_sd, n_epochs=meta["n_epochs"], n_cpu=0, latent_dim=meta["latent_dim"])
+    for k in ("generator", "discriminator", "dist"):
+        got, want = np.asarray(mine["losses"][k], dtype=np.float64), np.asarray(fx[f"loss_{k}"], dtype=np.float64)
+        assert got.shape == want.shape, k
+        assert np.allclose(got, want, rtol=2e-5, atol=1e-6), (k, got, want)
+    assert np.array_equal(mine["dumps"][1]["label"], fx["label"])
+    rs = mine["dumps"][1]["recon_x"].astype(np.float64).sum(1)
+    assert np.allclose(rs, fx["recon_x_rowsum"], rtol=1e-4, atol=1e-3)
+    assert abs(checksum(mine["G"]) - float(fx["g_checksum"])) <= 1e-5 * float(fx["g_checksum"])
+    assert abs(checksum(mine["D"]) - float(fx["d_checksum"])) <= 1e-5 * float(fx["d_checksum"])
 
 
 def test_oracle_fp64_agrees_with_fp32_fixture():
