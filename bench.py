@@ -67,7 +67,7 @@ def build_engine(args, rank, world, device):
     eng = TrainEngine(S, C, Z, B, float(dmin[0]), float(dmax[0]), G.state_dict(), D.state_dict(), F.state_dict(),
                       lr=2e-4, alpha=0.02, n_critic=3, penalty=args.penalty, device=device, seed=1234 + rank,
                       process_group=pg, world_size=world, overlap=bool(args.overlap), rank=rank, sync_bn=strong,
-                      operands=args.operands)
+                      operands=args.operands, wk=bool(args.wk))
     eng.attach_dataset(Xs, y, shuffle_seed=0 if strong else rank)
     return eng, (dmin.double().cpu().numpy(), dmax.double().cpu().numpy())
 
@@ -104,7 +104,7 @@ def gemm_roofline(eng, plans=None, rep=16, rounds=3):
     from wfd_gan_amd.plan import FORK, HOST, JOIN
     L = eng.L
     gemm_fns = {L.gemm_f32: "gemm", L.conv8_gemm_f32: "conv", L.gemm_f32_fused: "gemm_fused",
-                L.conv8_gemm_f32_fused: "conv", L.gemm_f32_pair: "pair"}
+                L.conv8_gemm_f32_fused: "conv", L.gemm_f32_pair: "pair", L.gemm_f32_wk: "gemm_wk", L.conv8_f32_wk: "conv"}
     calls = []
     for plan, weight in (plans or ((eng.fast_d, eng.n_critic), (eng.fast_g, 1))):
         for fn, a, _lane in plan.calls:
@@ -120,6 +120,8 @@ def gemm_roofline(eng, plans=None, rep=16, rounds=3):
                 M, N, K = a[8], a[9], a[10]
             elif kind == "gemm_fused":
                 M, N, K = a[7], a[8], a[9]
+            elif kind == "gemm_wk":
+                M, N, K = a[5], a[6], a[7]
             else:
                 M, N, K = a[1] * a[2], a[6], 8 * a[3]
             calls.append((fn, a, 2.0 * M * N * K, weight))
@@ -214,6 +216,9 @@ def main():
     ap.add_argument("--pipeline", type=int, default=0,
                     help="1: software-pipelined driver (wfd_gan_amd.engine.PipelinedTrainer; measured 3 %% slower than "
                          "the sequential engine on one MI355X, see DESIGN.md section 6); 0: sequential engine")
+    ap.add_argument("--wk", type=int, default=1,
+                    help="1: small-batch products with the K split inside the workgroup and the consumer fused into the "
+                         "store (gemm_wk.hip); 0: split-K slabs + consumer launches everywhere")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-sampling", action="store_true")
     ap.add_argument("--no-modes", action="store_true", help="skip the bf16x3 / bf16 operand-mode runs of the same step")
@@ -328,7 +333,8 @@ def main():
     peak = {"f32": PEAK_F32_MFMA_TFLOPS, "bf16": 2500.0, "bf16x3": 2500.0 / 3}[args.operands]
     dtype = {"f32": "f32", "bf16": "bf16 operands, f32 accumulate (data f32 in HBM)",
              "bf16x3": "f32 via split-bf16 (3 bf16 MFMAs per product), f32 accumulate"}[args.operands]
-    core = ("fp32 MFMA core: gemm_f32_kernel / gemm_f32_pair_kernel (all layouts, implicit-GEMM conv) + conv8_c32_kernel" if args.operands == "f32"
+    core = ("fp32 MFMA core: gemm_wk_kernel (small-batch products, K split inside the workgroup, fused consumers) + gemm_f32_kernel / "
+            "gemm_f32_pair_kernel (weight gradients, implicit-GEMM conv) + conv8_c32_kernel" if args.operands == "f32"
             else "bf16 MFMA core over fp32 data: gemm_mx_kernel (all layouts, implicit-GEMM conv)")
     # the same step with the contractions on the bf16 matrix pipe (gemm_mx.hip): reported beside the headline, never as
     # `value` (the headline stays the f32-operand parity path unless --operands says otherwise)
@@ -370,7 +376,7 @@ def main():
                        "samples_per_s": steps_per_s * eng.B * world,
                        "parallelism": f"dp{world}", "graphs": not args.no_graph, "pipelined": pipelined,
                        "grouped_generator_forwards": grouped, "length_index_saturated": saturated,
-                       "operands": args.operands},
+                       "operands": args.operands, "wk_fused_products": bool(args.wk)},
             "roofline": {"bound": "mfma", "achieved": roof["tflops"], "peak": peak, "unit": "TFLOP/s",
                          "frac": roof["tflops"] / peak, "traffic": traffic if args.operands == "f32" else None,
                          "traffic_note": "bytes/launch, rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command "

@@ -76,6 +76,25 @@ int wfd_conv8_gemm_f32_fused(const float* X, int Bn, int L, int Cin, int pad, co
                              int ldo, int epi, const float* scale, const float* shift, int act, const float* D, int ldd,
                              int dmode, void* stream);
 
+/* Small-batch form of the same contractions + consumers: the K split runs INSIDE the workgroup (one 32x32 or 32x16 output
+ * tile per workgroup, its 2-8 waves each contract a k-range with exact-f32 MFMAs and fold through LDS in wave order), so
+ * the consumer's math is applied in the store -- no slabs, no second launch.  layout 0 NT / 1 NN as wfd_gemm_f32.
+ *   epi 0: out = product (read by row / column reducing consumers as ONE slab);
+ *   epi 1: wfd_ep_affine_act (nn.Linear bias + ReLU, eval BatchNorm + ELU / ReLU, src/model.py:20-34,140-196);
+ *   epi 2: wfd_ep_mul, out2 = out * rowscale[m] when out2 != NULL (autograd.grad chain, src/mlp_df_wgan_train.py:204-213,229,273);
+ *   epi 3: wfd_ep_lrelu_drop with bias = shift, H = out, D = out2 (nn.LeakyReLU + nn.Dropout, src/model.py:58-65).
+ * Operands 16-byte aligned, lda / ldb multiples of 4.  cfg 0 = the library's choice (wfd_gemm_wk_pick), else 1..5.
+ * Results agree with the two-launch form to fp32 summation order (tests/test_gpu_gemm_wk.py). */
+int wfd_gemm_f32_wk(int layout, const float* A, int lda, const float* B, int ldb, int M, int N, int K, int epi, float* out,
+                    int ldo, float* out2, int ldo2, const float* scale, const float* shift, int act, const float* D, int ldd,
+                    int dmode, const float* rowscale, const float* mask, int ldmask, float slope, int cfg, void* stream);
+/* the k=8 "SAME" conv of wfd_conv8_gemm_f32 (src/model.py:92-105) in that form; Cin a multiple of 32; epi 0..2 */
+int wfd_conv8_f32_wk(const float* X, int Bn, int L, int Cin, int pad, const float* Wp, int Cout, int epi, float* out, int ldo,
+                     const float* scale, const float* shift, int act, const float* D, int ldd, int dmode, int cfg,
+                     void* stream);
+/* configuration the library picks for a product (layout 0 NT, 1 NN, 3 conv), 0 = use the slab form of wfd_gemm_f32 */
+int wfd_gemm_wk_pick(int layout, int M, int N, int K);
+
 /* bf16-operand MFMA (fp32 accumulate) NT product for the large-batch forward path (bulk sampling, BASELINE config
  * 4/5): A (M,K) and B (N,K) bf16 row-major, K and both leading dimensions multiples of 8, 16-byte aligned.
  * O != NULL: O = bf16(act(acc*scale[n]+shift[n])) (act 0 none, 1 ReLU, 3 sigmoid); else raw fp32 into P.

@@ -121,7 +121,9 @@ def test_grouped_heads_equal_sequential_replay(penalty):
     """GroupedTrainer: the generator forwards of the three iterations of a group run stacked (3*B rows, BatchNorm per
     batch).  Every iteration of two groups is replayed on a sequential engine from the same parameters with the
     batch / z / masks the grouped run used.  Not bit-identical (a 3*B-row GEMM splits K differently), so: generated
-    rows to 1e-5, updated parameters to 1e-5 of their scale, BatchNorm running statistics to 1e-5."""
+    rows and gradients to 1e-5 of their scale, updated parameters to 1e-3 of their scale (RMSprop's first steps,
+    lr g / (0.1 |g| + 1e-8), turn the rounding difference of a near-zero gradient into a visible fraction of the 10 lr
+    step; a wrong sign would be 4e-2), BatchNorm running statistics to 1e-5."""
     from wfd_gan_amd.engine import GroupedTrainer
     S, C, Z, B = 101, 6, 24, 16
     X, y = O.synth_dataset(C, 30, S - 1, 10, 13, 122, seed=1)
@@ -163,8 +165,11 @@ def test_grouped_heads_equal_sequential_replay(penalty):
             torch.cuda.synchronize()
             assert float((ref.fake_rows - s.fake_rows).abs().max()) < 1e-5, f"group {gi} slot {k}: generated rows"
             assert torch.equal(ref.buf["idx"], s.buf["idx"])
-            for a, bb, what in ((ref.Dp.flat, eng.Dp.flat, "critic"), (ref.Gp.flat, eng.Gp.flat, "generator")):
+            for a, bb, what in ((ref.Dp.grad, eng.Dp.grad, "critic gradients"),) + \
+                    (((ref.Gp.grad, eng.Gp.grad, "generator gradients"),) if k == 2 else ()):
                 assert float((a - bb).abs().max()) <= 1e-5 * float(a.abs().max()), f"group {gi} slot {k}: {what}"
+            for a, bb, what in ((ref.Dp.flat, eng.Dp.flat, "critic"), (ref.Gp.flat, eng.Gp.flat, "generator")):
+                assert float((a - bb).abs().max()) <= 1e-3 * float(a.abs().max()), f"group {gi} slot {k}: {what}"
         for k, v in eng.Gbuf.items():       # 3 forward updates + the G-step's, in order
             assert float((ref.Gbuf[k] - v).abs().max()) <= 1e-5 * max(1.0, float(v.abs().max())), k
     assert not int(eng.buf["err"].item())

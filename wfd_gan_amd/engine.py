@@ -169,7 +169,7 @@ class TrainEngine:
                  seed: int = 0, workspace_mb: int = 256, process_group=None, world_size: int = 1,
                  share: Optional["TrainEngine"] = None, overlap: bool = False, force_sync: bool = False,
                  sync_bn: bool = False, rank: int = 0, stacked: Optional[Dict[str, torch.Tensor]] = None,
-                 slot: int = 0, operands: str = "f32", pair: bool = True):
+                 slot: int = 0, operands: str = "f32", pair: bool = True, wk: bool = True):
         """Data parallel, two modes:
           * sync_bn=False (weak scaling, DDP semantics): every rank trains on its own ``batch`` rows with local
             BatchNorm statistics and a local selected-row count; gradients are averaged over ranks.
@@ -189,6 +189,8 @@ class TrainEngine:
         # pair: a weight gradient and the next product of the backward chain (independent of each other) go out as one
         # launch (Plan.gemm_pair) unless the two-stream schedule (overlap) is on
         self.pair = bool(pair) and not overlap
+        # wk: small-batch products with the K split inside the workgroup and the consumer fused into the store (gemm_wk.hip)
+        self.wk = bool(wk)
         self.L = lib()
         self.dev = torch.device(device)
         S, C, Z, B = seq_len, class_dim, latent_dim, batch
@@ -351,8 +353,8 @@ class TrainEngine:
     def _g_forward(self, p: Plan, nupd: int):
         """Generator.forward in training mode (src/model.py:36-48) -> fake rows of the critic input."""
         B, S, C, Z, b, G = self.B, self.S, self.C, self.Z, self.buf, self.Gp.p
-        s = p.gemm(NT, b["ZIN"], self.ldz, G["model.0.weight"], self.Gp.ld["model.0.weight"], B, 512, Z + C)
-        p.affine_act(s, None, G["model.0.bias"], ACT_RELU, b["GH1"], 512)
+        p.gemm_affine(NT, b["ZIN"], self.ldz, G["model.0.weight"], self.Gp.ld["model.0.weight"], B, 512, Z + C, None,
+                      G["model.0.bias"], ACT_RELU, b["GH1"], 512)
         prev, kprev = b["GH1"], 512
         for i, lin, bn, n in ((2, "model.2", "model.3", 1024), (3, "model.5", "model.6", 2048)):
             s = p.gemm(NT, prev, kprev, G[f"{lin}.weight"], kprev, B, n, kprev)
@@ -393,10 +395,10 @@ class TrainEngine:
     def _critic_forward(self, p: Plan, X, M: int, mk, H1, H2, H3, D1, D2, D3, V, DL3, DL3s, rowscale):
         """Discriminator.forward (src/model.py:69-72) on M rows of X, keeping d_i; ends with the head + delta_3."""
         S, C, D = self.S, self.C, self.Dp.p
-        s = p.gemm(NT, X, self.ldx, D["model.0.weight"], self.Dp.ld["model.0.weight"], M, 2048, S + C)
-        p.lrelu_drop(s, D["model.0.bias"], mk[0], 2048, H1, 2048, D1, 2048)
-        s = p.gemm(NT, H1, 2048, D["model.3.weight"], 2048, M, 1024, 2048)
-        p.lrelu_drop(s, D["model.3.bias"], mk[1], 1024, H2, 1024, D2, 1024)
+        p.gemm_lrelu_drop(NT, X, self.ldx, D["model.0.weight"], self.Dp.ld["model.0.weight"], M, 2048, S + C,
+                          D["model.0.bias"], mk[0], 2048, H1, 2048, D1, 2048)
+        p.gemm_lrelu_drop(NT, H1, 2048, D["model.3.weight"], 2048, M, 1024, 2048, D["model.3.bias"], mk[1], 1024, H2, 1024,
+                          D2, 1024)
         s = p.gemm(NT, H2, 1024, D["model.6.weight"], 1024, M, 512, 1024)
         # layer-3 epilogue + head (nn.Linear(512, 1)) + first step of the input-gradient chain in one launch
         p.add(self.L.d_head_lrelu, s.ptr, s.ns, s.ss, s.ldp, ptr(D["model.6.bias"]), ptr(mk[2]), 512, 0.2, ptr(H3), 512,
@@ -406,10 +408,10 @@ class TrainEngine:
     def _critic_chain(self, p: Plan, M: int, DL3, DL2, DL2s, DL1, DL1s, D2, D1, rowscale) -> Slabs:
         """d validity / d traces in closed form; returns the slabs of g = (delta_1 W_1)[:, :S]."""
         S, C, D = self.S, self.C, self.Dp.p
-        s = p.gemm(NN, DL3, 512, D["model.6.weight"], 1024, M, 1024, 512)
-        p.mul(s, D2, 1024, DM_MUL, None, rowscale, DL2, DL2s, 1024)
-        s = p.gemm(NN, DL2, 1024, D["model.3.weight"], 2048, M, 2048, 1024)
-        p.mul(s, D1, 2048, DM_MUL, None, rowscale, DL1, DL1s, 2048)
+        p.gemm_mul(NN, DL3, 512, D["model.6.weight"], 1024, M, 1024, 512, D2, 1024, DM_MUL, None, DL2, 1024,
+                   rowscale=rowscale, out2=DL2s)
+        p.gemm_mul(NN, DL2, 1024, D["model.3.weight"], 2048, M, 2048, 1024, D1, 2048, DM_MUL, None, DL1, 2048,
+                   rowscale=rowscale, out2=DL1s)
         return p.gemm(NN, DL1, 2048, D["model.0.weight"], self.Dp.ld["model.0.weight"], M, S, 2048)
 
     GOLD = 0x9E3779B97F4A7C15
@@ -424,7 +426,7 @@ class TrainEngine:
         part: "all" = the whole D-step; "gf" = only its head (batch gather, z / mask draws, generator forward), which
         depends on nothing the critic update writes; "rest" = everything after it (PipelinedTrainer)."""
         B, M, S, C, Z, b, D = self.B, self.M, self.S, self.C, self.Z, self.buf, self.Dp
-        p = Plan(b["ws"] if part != "gf" else b["ws_gf"], b["ws2"], self.overlap, self.gemm_mode)
+        p = Plan(b["ws"] if part != "gf" else b["ws_gf"], b["ws2"], self.overlap, self.gemm_mode, self.wk)
         st = self.iter_state.data_ptr() if part != "gf" else self.gf_state.data_ptr()
         if part in ("rest", "rest_draw"):
             if part == "rest_draw":
@@ -486,17 +488,17 @@ class TrainEngine:
         if self.pair:
             # each layer's weight gradient (one TN product over the stacked [penalty ; standard] rows) shares a launch
             # with the t-chain product that follows it: neither reads what the other writes
-            s = p.gemm_pair((b["DL1"], 2048, b["XC"], self.ldx, 2048, S + C, 2 * M, D.g["model.0.weight"], D.ld["model.0.weight"]),
-                            (NT, b["XC"], self.ldx, Dp["model.0.weight"], D.ld["model.0.weight"], M, 2048, S))
+            p.gemm_pair_mul((b["DL1"], 2048, b["XC"], self.ldx, 2048, S + C, 2 * M, D.g["model.0.weight"], D.ld["model.0.weight"]),
+                            (NT, b["XC"], self.ldx, Dp["model.0.weight"], D.ld["model.0.weight"], M, 2048, S),
+                            b["D1"], 2048, DM_MUL, b["T1H1"][:M], 2048)
             self._grad_bucket_hook(p, "D", 0)
-            p.mul(s, b["D1"], 2048, DM_MUL, None, None, b["T1H1"][:M], None, 2048)
-            s = p.gemm_pair((b["DL2"], 1024, b["T1H1"], 2048, 1024, 2048, 2 * M, D.g["model.3.weight"], 2048),
-                            (NT, b["T1H1"][:M], 2048, Dp["model.3.weight"], 2048, M, 1024, 2048))
+            p.gemm_pair_mul((b["DL2"], 1024, b["T1H1"], 2048, 1024, 2048, 2 * M, D.g["model.3.weight"], 2048),
+                            (NT, b["T1H1"][:M], 2048, Dp["model.3.weight"], 2048, M, 1024, 2048),
+                            b["D2"], 1024, DM_MUL, b["T2H2"][:M], 1024)
             self._grad_bucket_hook(p, "D", 1)
-            p.mul(s, b["D2"], 1024, DM_MUL, None, None, b["T2H2"][:M], None, 1024)
-            s = p.gemm_pair((b["DL3"], 512, b["T2H2"], 1024, 512, 1024, 2 * M, D.g["model.6.weight"], 1024),
-                            (NT, b["T2H2"][:M], 1024, Dp["model.6.weight"], 1024, M, 512, 1024))
-            p.mul(s, b["D3"], 512, DM_MUL, None, None, b["T3"], None, 512)
+            p.gemm_pair_mul((b["DL3"], 512, b["T2H2"], 1024, 512, 1024, 2 * M, D.g["model.6.weight"], 1024),
+                            (NT, b["T2H2"][:M], 1024, Dp["model.6.weight"], 1024, M, 512, 1024),
+                            b["D3"], 512, DM_MUL, b["T3"], 512)
         else:
             self._d_backward_two_lane(p)
         self._colsum_multi(p, "d_small", bias_segs + [
@@ -597,12 +599,9 @@ class TrainEngine:
               b["ghead"].data_ptr() + 4, self.alpha, ptr(b["CE"]), ptr(b["DLOG"]), self.ldc)
         p.add(self.L.g_loss, ptr(b["CE"]), B, ptr(b["ghead"]), self.alpha, ptr(b["gstats"]), ptr(b["gacc"]))
         # ---- input gradient
-        s = p.gemm(NN, b["DLOG"], self.ldc, df.fc_w, 512, B, 512, self.C)
-        p.mul(s, b["F2"], 512, DM_RELU, df.fc2_scale, None, b["DF2"], None, 512)
-        s = p.gemm(NN, b["DF2"], 512, df.fc2_w, 512, B, 512, 512)
-        p.mul(s, b["F1"], 512, DM_RELU, df.fc1_scale, None, b["DF1"], None, 512)
-        s = p.gemm(NN, b["DF1"], 512, df.fc1_w, kin, B, kin, 512)
-        p.mul(s, None, 0, DM_NONE, None, None, DPO[3], None, kin)
+        p.gemm_mul(NN, b["DLOG"], self.ldc, df.fc_w, 512, B, 512, self.C, b["F2"], 512, DM_RELU, df.fc2_scale, b["DF2"], 512)
+        p.gemm_mul(NN, b["DF2"], 512, df.fc2_w, 512, B, 512, 512, b["F1"], 512, DM_RELU, df.fc1_scale, b["DF1"], 512)
+        p.gemm_mul(NN, b["DF1"], 512, df.fc1_w, kin, B, kin, 512, None, 0, DM_NONE, None, DPO[3], kin)
         # walk the conv stack backwards; `lvl` = index of the length the conv runs at
         k, lvl, pi = 6, 3, 3
         while k >= 1:
@@ -633,7 +632,7 @@ class TrainEngine:
 
     def _build_g_plan(self, fast: bool = False, draw_masks: bool = True) -> Plan:
         B, S, C, Z, b, G = self.B, self.S, self.C, self.Z, self.buf, self.Gp
-        p = Plan(b["ws"], b["ws2"], self.overlap, self.gemm_mode)
+        p = Plan(b["ws"], b["ws2"], self.overlap, self.gemm_mode, self.wk)
         st = self.iter_state.data_ptr()
         if fast and draw_masks:
             t = b["gMKflat"]
@@ -672,9 +671,9 @@ class TrainEngine:
                         (NN, b["GDZ3"], 2048, Gp["model.5.weight"], 1024, B, 1024, 2048), pair=pr)
         self._grad_bucket_hook(p, "G", 1)
         self._bn_bwd(p, s, 2, "model.2", "model.3", 1024)
-        s = p.gemm_pair((b["GDZ2"], 1024, b["GH1"], 512, 1024, 512, B, G.g["model.2.weight"], 512),
-                        (NN, b["GDZ2"], 1024, Gp["model.2.weight"], 512, B, 512, 1024), pair=pr)
-        p.mul(s, b["GH1"], 512, DM_RELU, None, None, b["GDZ1"], None, 512)
+        p.gemm_pair_mul((b["GDZ2"], 1024, b["GH1"], 512, 1024, 512, B, G.g["model.2.weight"], 512),
+                        (NN, b["GDZ2"], 1024, Gp["model.2.weight"], 512, B, 512, 1024), b["GH1"], 512, DM_RELU, b["GDZ1"], 512,
+                        pair=pr)
         p.add(self.L.colsum, ptr(b["GDZ1"]), 512, B, 512, 0, ptr(G.g["model.0.bias"]), 0)
         p.gemm(TN, b["GDZ1"], 512, b["ZIN"], self.ldz, 512, Z + C, B, out=G.g["model.0.weight"],
                ldp=G.ld["model.0.weight"])
@@ -967,7 +966,7 @@ class PipelinedTrainer:
         self.e = [eng, TrainEngine(eng.S, eng.C, eng.Z, eng.B, eng.scaler_min, eng.scaler_max, {}, {}, {}, lr=eng.lr,
                                    alpha=eng.alpha, n_critic=eng.n_critic, penalty=eng.penalty, lambda_gp=eng.lambda_gp,
                                    device=eng.dev, seed=eng.seed + 0x51ED, process_group=eng.pg, world_size=eng.world,
-                                   share=eng, rank=eng.rank, operands=eng.operands)]
+                                   share=eng, rank=eng.rank, operands=eng.operands, wk=eng.wk)]
         other = self.e[1]
         for name in ("data_X", "data_y", "N", "perm", "perm_gen", "iters_per_epoch"):
             setattr(other, name, getattr(eng, name))
@@ -1096,7 +1095,7 @@ class GroupedTrainer:
         self.e = [TrainEngine(eng.S, eng.C, eng.Z, eng.B, eng.scaler_min, eng.scaler_max, {}, {}, {}, lr=eng.lr,
                               alpha=eng.alpha, n_critic=n, penalty=eng.penalty, lambda_gp=eng.lambda_gp, device=dev,
                               seed=eng.seed + 0x9E37 * (k + 1), process_group=eng.pg, world_size=eng.world, share=eng,
-                              rank=eng.rank, stacked=self.stacked, slot=k, operands=eng.operands) for k in range(n)]
+                              rank=eng.rank, stacked=self.stacked, slot=k, operands=eng.operands, wk=eng.wk) for k in range(n)]
         self.base = eng
         for e in self.e:
             for name in ("data_X", "data_y", "N", "perm", "perm_gen", "iters_per_epoch"):
@@ -1107,7 +1106,7 @@ class GroupedTrainer:
         self.head = self._build_head()
         self.rest = [e._build_d_plan(fast=True, part="rest_draw", draw_masks=not self.merged_masks) for e in self.e]
         self.gstep = self.e[n - 1]._build_g_plan(fast=True, draw_masks=not self.merged_masks)
-        self.group = Plan(self.ws, gemm_mode=eng.gemm_mode)
+        self.group = Plan(self.ws, gemm_mode=eng.gemm_mode, wk=eng.wk)
         self.group.extend(self.head)
         for r in self.rest:
             self.group.extend(r)
@@ -1122,7 +1121,7 @@ class GroupedTrainer:
         eng, n, L = self.base, self.n, self.base.L
         B, S, C, Z, G, st = eng.B, eng.S, eng.C, eng.Z, eng.Gp.p, self.stacked
         M = n * B
-        p = Plan(self.ws, gemm_mode=eng.gemm_mode)
+        p = Plan(self.ws, gemm_mode=eng.gemm_mode, wk=eng.wk)
         # the dropout keep-masks of the group's n critic passes and of its G-step in one launch: the same numbers the
         # iterations would draw themselves (iteration k starts k optimizer steps, i.e. k counter increments, after this
         # point; the G-step after all n)
@@ -1144,8 +1143,8 @@ class GroupedTrainer:
               B, n, eng.cursor_step, S, C, ptr(real0), ptr(fake0), eng.ldx, slot_stride, ptr(st["ZIN"]), eng.ldz, Z,
               ptr(st["labels"]))
         p.add(L.rng_normal_rows, ptr(st["ZIN"]), eng.ldz, M, Z, (eng.seed + 7 * eng.GOLD) & (2**64 - 1), state, 0)
-        s = p.gemm(NT, st["ZIN"], eng.ldz, G["model.0.weight"], eng.Gp.ld["model.0.weight"], M, 512, Z + C)
-        p.affine_act(s, None, G["model.0.bias"], ACT_RELU, st["GH1"], 512)
+        p.gemm_affine(NT, st["ZIN"], eng.ldz, G["model.0.weight"], eng.Gp.ld["model.0.weight"], M, 512, Z + C, None,
+                      G["model.0.bias"], ACT_RELU, st["GH1"], 512)
         prev, kprev = st["GH1"], 512
         for i, lin, bn, width in ((2, "model.2", "model.3", 1024), (3, "model.5", "model.6", 2048)):
             s = p.gemm(NT, prev, kprev, G[f"{lin}.weight"], kprev, M, width, kprev)

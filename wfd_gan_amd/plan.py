@@ -46,8 +46,11 @@ class Plan:
     _side_streams = {}
 
     def __init__(self, workspace: torch.Tensor, side_workspace: Optional[torch.Tensor] = None, overlap: bool = True,
-                 gemm_mode: int = 0):
+                 gemm_mode: int = 0, wk: bool = True):
         self.L = lib()
+        # wk: small-batch products run with the K split inside the workgroup and their consumer fused into the store
+        # (wfd_gemm_f32_wk: one launch, no slabs) wherever the library picks that form; f32 operand mode only
+        self.wk = bool(wk) and int(gemm_mode) == 0
         # operand mode of the plan's contractions (include/wfdgan.h, wfd_set_gemm_mode): 0 f32-input MFMA (parity path),
         # 1 bf16 operands, 2 split-bf16 x3.  Set around run(), so plans of different modes can coexist in a process.
         self.gemm_mode = int(gemm_mode)
@@ -139,7 +142,7 @@ class Plan:
 
     def stages(self):
         """[Plan | thunk, ...]: maximal runs of launches separated by host actions."""
-        mk = lambda: Plan(self.ws_lane[0], self.ws_lane[1] if self.two else None, self.overlap, self.gemm_mode)
+        mk = lambda: Plan(self.ws_lane[0], self.ws_lane[1] if self.two else None, self.overlap, self.gemm_mode, self.wk)
         out, cur = [], mk()
         for fn, a, lane in self.calls:
             if fn is HOST:
@@ -157,9 +160,33 @@ class Plan:
         return len(self.calls)
 
     # -- contractions -------------------------------------------------------------------------------------
+    def wk_cfg(self, layout: int, A, lda: int, B, ldb: int, M: int, N: int, K: int) -> int:
+        """Configuration of the split-inside-the-workgroup form for this product, 0 = use the slab form."""
+        if not self.wk or layout not in (NT, NN):
+            return 0
+        if ptr(A) % 16 or ptr(B) % 16 or lda % 4 or ldb % 4:
+            return 0
+        return self.L.gemm_wk_pick(layout, M, N, K)
+
+    def _wk(self, layout, A, lda, B, ldb, M, N, K, cfg, epi, out, ldo, out2=None, ldo2=0, scale=None, shift=None, act=0,
+            D=None, ldd=0, dmode=0, rowscale=None, mask=None, ldmask=0, slope=0.0):
+        self.add(self.L.gemm_f32_wk, layout, ptr(A), lda, ptr(B), ldb, M, N, K, epi, ptr(out), ldo, ptr(out2), ldo2,
+                 ptr(scale), ptr(shift), act, ptr(D), ldd, dmode, ptr(rowscale), ptr(mask), ldmask, slope, cfg)
+
     def gemm(self, layout: int, A, lda: int, B, ldb: int, M: int, N: int, K: int, out=None, ldp: Optional[int] = None,
              splits: Optional[int] = None) -> Slabs:
         """Raw product into the slab workspace (or straight into ``out`` with splits = 1)."""
+        cfg = self.wk_cfg(layout, A, lda, B, ldb, M, N, K) if splits is None else 0
+        if cfg:
+            # one launch, one "slab": the row / column reducing consumers (BatchNorm, head, penalty) read it as such
+            if out is None:
+                ldp = rup(N, 4)
+                if M * ldp > self.ws_floats:
+                    raise RuntimeError("slab workspace too small")
+                self._wk(layout, A, lda, B, ldb, M, N, K, cfg, 0, self.ws, ldp)
+                return Slabs(ptr(self.ws), 1, M * ldp, ldp, M, N)
+            self._wk(layout, A, lda, B, ldb, M, N, K, cfg, 0, out, ldp)
+            return Slabs(ptr(out), 1, 0, ldp, M, N)
         if out is not None:
             # a long contraction that alone cannot fill the chip (weight gradients of a large batch: K = rows of the
             # batch) is split over K into slabs and summed into `out`; short ones go straight into `out`
@@ -221,28 +248,72 @@ class Plan:
 
     # -- contraction + element-wise consumer: fused into one launch when a single split fills the chip ------------
     def gemm_affine(self, layout, A, lda, B, ldb, M, N, K, scale, shift, act, out, ldo):
-        if self.pick_splits(M, N, K) == 1:
+        cfg = self.wk_cfg(layout, A, lda, B, ldb, M, N, K)
+        if cfg:
+            self._wk(layout, A, lda, B, ldb, M, N, K, cfg, 1, out, ldo, scale=scale, shift=shift, act=act)
+        elif self.pick_splits(M, N, K) == 1:
             self.add(self.L.gemm_f32_fused, layout, ptr(A), lda, ptr(B), ldb, ptr(out), ldo, M, N, K, 1, ptr(scale),
                      ptr(shift), act, 0, 0, 0)
         else:
             self.affine_act(self.gemm(layout, A, lda, B, ldb, M, N, K), scale, shift, act, out, ldo)
 
-    def gemm_mul(self, layout, A, lda, B, ldb, M, N, K, D, ldd, dmode, colscale, out, ldo):
-        if self.pick_splits(M, N, K) == 1:
+    def gemm_mul(self, layout, A, lda, B, ldb, M, N, K, D, ldd, dmode, colscale, out, ldo, rowscale=None, out2=None):
+        """out = product * f(D) * colscale[n]; out2 = out * rowscale[m] (wfd_ep_mul's math) in as few launches as the shape
+        allows."""
+        cfg = self.wk_cfg(layout, A, lda, B, ldb, M, N, K)
+        if cfg:
+            self._wk(layout, A, lda, B, ldb, M, N, K, cfg, 2, out, ldo, out2=out2, ldo2=ldo, scale=colscale, D=D, ldd=ldd,
+                     dmode=dmode, rowscale=rowscale if out2 is not None else None)
+        elif self.pick_splits(M, N, K) == 1 and out2 is None:
             self.add(self.L.gemm_f32_fused, layout, ptr(A), lda, ptr(B), ldb, ptr(out), ldo, M, N, K, 2, ptr(colscale),
                      0, 0, ptr(D), ldd, dmode)
         else:
-            self.mul(self.gemm(layout, A, lda, B, ldb, M, N, K), D, ldd, dmode, colscale, None, out, None, ldo)
+            self.mul(self.gemm(layout, A, lda, B, ldb, M, N, K), D, ldd, dmode, colscale, rowscale, out, out2, ldo)
+
+    def gemm_lrelu_drop(self, layout, A, lda, B, ldb, M, N, K, bias, mask, ldmask, H, ldh, D, ldd, slope: float = 0.2):
+        """A critic hidden layer (product + wfd_ep_lrelu_drop's math)."""
+        cfg = self.wk_cfg(layout, A, lda, B, ldb, M, N, K)
+        if cfg:
+            self._wk(layout, A, lda, B, ldb, M, N, K, cfg, 3, H, ldh, out2=D, ldo2=ldd, shift=bias, mask=mask, ldmask=ldmask,
+                     slope=slope)
+        else:
+            self.lrelu_drop(self.gemm(layout, A, lda, B, ldb, M, N, K), bias, mask, ldmask, H, ldh, D, ldd, slope)
+
+    def gemm_pair_mul(self, tn, other, D, ldd, dmode, out, ldo, pair: bool = True):
+        """A weight gradient (tn, written in full) and the next product of the backward chain with its `o d` factor applied:
+        TN launch + one fused launch where the split-inside-the-workgroup form applies, else the pair launch (or two
+        launches) + wfd_ep_mul."""
+        lay, A2, lda2, B2, ldb2, M2, N2, K2 = other
+        cfg = self.wk_cfg(lay, A2, lda2, B2, ldb2, M2, N2, K2)
+        if cfg:
+            A1, lda1, B1, ldb1, M1, N1, K1, o1, ldp1 = tn
+            self.gemm(TN, A1, lda1, B1, ldb1, M1, N1, K1, out=o1, ldp=ldp1)
+            self._wk(lay, A2, lda2, B2, ldb2, M2, N2, K2, cfg, 2, out, ldo, D=D, ldd=ldd, dmode=dmode)
+        else:
+            self.mul(self.gemm_pair(tn, other, pair=pair), D, ldd, dmode, None, None, out, None, ldo)
+
+    def conv_wk_cfg(self, X, Wp, M: int, Cin: int, Cout: int) -> int:
+        if not self.wk or Cin % 32 or ptr(X) % 16 or ptr(Wp) % 16 or self.L.conv8_direct_mode(M, Cin, Cout, self.gemm_mode):
+            return 0
+        return self.L.gemm_wk_pick(3, M, Cout, 8 * Cin)
 
     def conv8_affine(self, X, Bn, L, Cin, pad, Wp, Cout, scale, shift, act, out):
-        if self.pick_splits(Bn * L, Cout, 8 * Cin) == 1 or self.L.conv8_direct_mode(Bn * L, Cin, Cout, self.gemm_mode):
+        cfg = self.conv_wk_cfg(X, Wp, Bn * L, Cin, Cout)
+        if cfg:
+            self.add(self.L.conv8_f32_wk, ptr(X), Bn, L, Cin, pad, ptr(Wp), Cout, 1, ptr(out), Cout, ptr(scale), ptr(shift), act,
+                     0, 0, 0, cfg)
+        elif self.pick_splits(Bn * L, Cout, 8 * Cin) == 1 or self.L.conv8_direct_mode(Bn * L, Cin, Cout, self.gemm_mode):
             self.add(self.L.conv8_gemm_f32_fused, ptr(X), Bn, L, Cin, pad, ptr(Wp), Cout, ptr(out), Cout, 1, ptr(scale),
                      ptr(shift), act, 0, 0, 0)
         else:
             self.affine_act(self.conv8(X, Bn, L, Cin, pad, Wp, Cout), scale, shift, act, out, Cout)
 
     def conv8_mul(self, X, Bn, L, Cin, pad, Wp, Cout, D, ldd, dmode, colscale, out):
-        if self.pick_splits(Bn * L, Cout, 8 * Cin) == 1 or self.L.conv8_direct_mode(Bn * L, Cin, Cout, self.gemm_mode):
+        cfg = self.conv_wk_cfg(X, Wp, Bn * L, Cin, Cout)
+        if cfg:
+            self.add(self.L.conv8_f32_wk, ptr(X), Bn, L, Cin, pad, ptr(Wp), Cout, 2, ptr(out), Cout, ptr(colscale), 0, 0,
+                     ptr(D), ldd, dmode, cfg)
+        elif self.pick_splits(Bn * L, Cout, 8 * Cin) == 1 or self.L.conv8_direct_mode(Bn * L, Cin, Cout, self.gemm_mode):
             self.add(self.L.conv8_gemm_f32_fused, ptr(X), Bn, L, Cin, pad, ptr(Wp), Cout, ptr(out), Cout, 2,
                      ptr(colscale), 0, 0, ptr(D), ldd, dmode)
         else:
