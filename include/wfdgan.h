@@ -282,6 +282,14 @@ int wfd_colminmax_f64(const double* X, long N, int S, double* part, int max_chun
 int wfd_minmax_transform_f64(const double* X, long N, int S, const double* scale, const double* min_, float* out,
                              void* stream);
 
+/* checkpoint dump, src/mlp_df_wgan_train.py:291-292: total_real = scaler.inverse_transform(scaler.transform(x)) in float64
+ * (four in-place passes, one rounding each) and total_fake = scaler.inverse_transform(float32 generated rows) (each pass in
+ * double, rounded to float32); bit-identical to sklearn (tests/test_gpu_tail.py) */
+int wfd_minmax_roundtrip_f64(const double* X, long N, int S, const double* scale, const double* min_, double* out,
+                             void* stream);
+int wfd_minmax_inverse_f32(const float* Y, int ldy, long M, int S, const double* scale, const double* min_, float* out,
+                           void* stream);
+
 /* --clip: my_clip over every row, src/mlp_df_wgan_train.py:82-91,122 (float64, in place) */
 int wfd_clip_bursts(double* X, long N, int S, double max_len, double max_out, double max_in, void* stream);
 

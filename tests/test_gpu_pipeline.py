@@ -175,6 +175,62 @@ def test_grouped_heads_equal_sequential_replay(penalty):
     assert not int(eng.buf["err"].item())
 
 
+def test_parity_plan_survives_rebuilds_of_the_step_plans():
+    """Every plan owns the descriptor table its merged column-sum launch reads (Plan.keep).  Building further D plans on
+    the same engine (attach_dataset, the pipelined / grouped drivers) must leave the parity-mode plan intact: d_step() after
+    those rebuilds equals d_step() on a fresh engine, bit for bit."""
+    from wfd_gan_amd.engine import GroupedTrainer, PipelinedTrainer
+    S, C, Z, B = 61, 4, 16, 8
+    X, y = O.synth_dataset(C, 20, S - 1, 10, 13, 122, seed=1)
+    dmin, dmax = X.min(0), X.max(0)
+    scale, min_ = O.scaler_params(dmin, dmax)
+    Xs = torch.from_numpy(X * scale + min_).float()
+    g = torch.Generator().manual_seed(0)
+    z = torch.randn(B, Z, generator=g)
+    masks = [(torch.rand(2 * B, n, generator=g) > 0.2).float() * 1.25 for n in (2048, 1024, 512)]
+    outs = []
+    for rebuild in (False, True):
+        st = O.make_state(S, C, Z, dmin[0], dmax[0], seed=2, df_seed=3)
+        eng = _engine(S, C, Z, B, st, seed=3)
+        if rebuild:
+            eng.attach_dataset(Xs, torch.from_numpy(y), shuffle_seed=5)      # builds fast_d / fast_g
+            PipelinedTrainer(eng, graphs=False)                              # builds "gf" / "rest" plans on eng
+            GroupedTrainer(eng, graphs=False)
+            junk = [torch.full((64,), -1, dtype=torch.int64, device=eng.dev) for _ in range(64)]   # reuse freed blocks
+            del junk
+        eng.set_batch(Xs[:B], torch.from_numpy(y[:B]), z)
+        eng.set_masks(masks, None)
+        eng.d_step()
+        torch.cuda.synchronize()
+        outs.append((eng.Dp.flat.clone(), eng.Dp.grad.clone(), eng.buf["dstats"].clone()))
+    for a, b in zip(*outs):
+        assert torch.equal(a, b)
+
+
+def test_grouped_head_noise_differs_from_single_iteration_noise():
+    """The trainer runs iteration 0 of an epoch on the single-iteration plan and iterations 1.. on the stacked heads; both
+    z streams count from 0, so they must use different Philox keys: iteration 1 must not repeat iteration 0's noise."""
+    from wfd_gan_amd.engine import GroupedTrainer
+    S, C, Z, B = 61, 4, 16, 8
+    X, y = O.synth_dataset(C, 20, S - 1, 10, 13, 122, seed=1)
+    dmin, dmax = X.min(0), X.max(0)
+    scale, min_ = O.scaler_params(dmin, dmax)
+    st = O.make_state(S, C, Z, dmin[0], dmax[0], seed=2, df_seed=3)
+    eng = _engine(S, C, Z, B, st, seed=3)
+    eng.attach_dataset(torch.from_numpy(X * scale + min_).float(), torch.from_numpy(y), shuffle_seed=5)
+    grp = GroupedTrainer(eng, graphs=False)
+    eng.iteration(0)
+    torch.cuda.synchronize()
+    z0 = eng.buf["ZIN"][:, :Z].clone()
+    grp.run_group()
+    torch.cuda.synchronize()
+    zs = [grp.slot(k).buf["ZIN"][:, :Z].clone() for k in range(3)]
+    for k, zk in enumerate(zs):
+        assert not torch.equal(z0, zk), f"slot {k} repeats iteration 0's noise"
+        assert abs(float(zk.mean())) < 0.5 and 0.5 < float(zk.std()) < 1.5
+    assert not torch.equal(zs[0], zs[1]) and not torch.equal(zs[1], zs[2])
+
+
 def test_grouped_graph_equals_eager():
     from wfd_gan_amd.engine import GroupedTrainer
     S, C, Z, B = 61, 4, 16, 8

@@ -1,0 +1,139 @@
+"""GPU: the per-epoch tail of the trainer and the module shells against the oracle.
+
+* test_DF_acc_epoch (src/mlp_df_wgan_train.py:57-79)  -> mlp_df_wgan_train.df_accuracy  vs oracle.train_loop.df_acc_epoch
+* checkpoint dump (:288-297)                           -> mlp_df_wgan_train.epoch_dump   vs sklearn's MinMaxScaler (bit-equal)
+* MyConv1dPadSame / MyMaxPool1dPadSame / DF.forward in train mode (src/model.py:92-105,119-132,198-206) vs torch / the oracle
+* the sampler's err flag: IndexError where the reference's Generator.forward raises (src/model.py:44)
+"""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from oracle import df_train as DT
+from oracle import train_loop as TL
+from oracle import wfdgan_oracle as O
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+def _df(length, C, seed):
+    from wfd_gan_amd.model import DF
+    torch.manual_seed(seed)
+    sd = O.make_df_state(length, C)
+    O.perturb_df_bn(sd, seed + 1)
+    m = DF(length, C)
+    m.load_state_dict(sd)
+    return m, sd
+
+
+@pytest.mark.parametrize("geom", [(500, 10, 333), (1400, 100, 300), (64, 5, 129)])
+def test_df_accuracy_matches_oracle(geom):
+    """A fixed block of "generated" rows + labels through the trainer's df_accuracy (device-side count, batches of 128
+    with a ragged last one) and through the oracle's restatement of test_DF_acc_epoch: the same number of correct rows.
+    Labels are the oracle's own prediction on half of the rows, so the accuracy is neither 0 nor 1."""
+    from wfd_gan_amd.mlp_df_wgan_train import df_accuracy
+    length, C, N = geom
+    m, sd = _df(length, C, seed=7)
+    m.eval().to(DEV)
+    g = torch.Generator().manual_seed(3)
+    rows = torch.rand(N, length + 1, generator=g)
+    rows = rows * (torch.arange(length + 1) < torch.randint(length // 4, length, (N, 1), generator=g)).float()
+    with torch.no_grad():
+        pred = O.df_forward(sd, rows[:, 1:].unsqueeze(1)).argmax(1)
+    labels = torch.randint(0, C, (N,), generator=g)
+    labels[::2] = pred[::2]
+    want = TL.df_acc_epoch(sd, list(rows.numpy()), list(labels.numpy()))
+    got = df_accuracy(m, rows.to(DEV), labels.to(DEV))
+    assert 0.3 < want < 0.9
+    assert round(got * N) == round(want * N), (got, want)
+
+
+def test_epoch_dump_bit_equal_to_sklearn():
+    from sklearn import preprocessing
+    from wfd_gan_amd.mlp_df_wgan_train import epoch_dump
+    X, _ = O.synth_dataset(7, 30, 200, 10, 75, 179, seed=4)
+    X[:, 9] = 5.0                                  # a constant column: scale_ = 1
+    scaler = preprocessing.MinMaxScaler().fit(X)
+    g = torch.Generator().manual_seed(1)
+    fake = torch.rand(150, 201, generator=g)
+    fake[:, 100:] = 0.0
+    sel = np.random.RandomState(0).permutation(X.shape[0])[:150]
+    want_real = scaler.inverse_transform(scaler.transform(X[sel]))               # :291, float64
+    want_fake = scaler.inverse_transform(fake.numpy().copy())                    # :292, float32
+    real, recon = epoch_dump(scaler, X[sel], fake.to(DEV))
+    assert real.dtype == np.float64 and recon.dtype == np.float32 == want_fake.dtype
+    assert np.array_equal(real, want_real)
+    assert np.array_equal(recon, want_fake)
+
+
+@pytest.mark.parametrize("geom", [(3, 1, 32, 77), (2, 32, 64, 175), (2, 64, 64, 40), (1, 128, 256, 3), (2, 4, 8, 19)])
+def test_conv_and_pool_shells_match_torch(geom):
+    """MyConv1dPadSame.forward / MyMaxPool1dPadSame.forward on NCL tensors vs F.pad (3, 4) + conv1d / max_pool1d(8)."""
+    from wfd_gan_amd.model import MyConv1dPadSame, MyMaxPool1dPadSame
+    B, cin, cout, Ln = geom
+    torch.manual_seed(B + cin + Ln)
+    conv = MyConv1dPadSame(cin, cout, 8, 1)
+    x = torch.randn(B, cin, Ln)
+    want = F.conv1d(F.pad(x.double(), (3, 4)), conv.conv.weight.detach().double(), conv.conv.bias.detach().double())
+    got = conv.to(DEV)(x.to(DEV))
+    assert got.shape == want.shape
+    assert (got.double().cpu() - want).abs().max().item() < 2e-5 * max(1.0, want.abs().max().item())
+    pool = MyMaxPool1dPadSame(8, 1)
+    y = F.elu(x)                                   # negative values: the ZERO padding must win over them (src/model.py:123-130)
+    wantp = F.max_pool1d(F.pad(y, (3, 4)), 8)
+    gotp = pool(y.to(DEV))
+    assert gotp.shape == wantp.shape and torch.equal(gotp.cpu(), wantp)
+    with pytest.raises(RuntimeError):
+        conv(x)                                    # CPU tensor: no fallback
+
+
+def test_df_forward_train_mode_matches_oracle():
+    """DF.forward in train mode (batch-statistics BatchNorm, dropout with injected masks) vs oracle.df_forward_train, incl.
+    the running statistics and num_batches_tracked the call leaves behind; then eval mode sees the updated statistics."""
+    length, C, B = 64, 5, 16
+    m, sd = _df(length, C, seed=11)
+    m.to(DEV).train()
+    g = torch.Generator().manual_seed(5)
+    x = torch.rand(B, 1, length, generator=g)
+    masks = [((torch.rand(s, generator=g) > p).float() / (1.0 - p)) for s, p in zip(DT.dropout_mask_shapes(length, B), DT.DROPOUT_P)]
+    ref_sd = {k: v.clone() for k, v in sd.items()}
+    want = DT.df_forward_train(ref_sd, x, masks).detach()
+    m.masks = masks
+    got = m(x.to(DEV)).cpu()
+    assert (got - want).abs().max().item() < 1e-4 * max(1.0, want.abs().max().item())
+    msd = m.state_dict()
+    for k, v in ref_sd.items():
+        if k.endswith("running_mean") or k.endswith("running_var"):
+            assert (msd[k].cpu() - v).abs().max().item() < 1e-5 * max(1.0, v.abs().max().item()), k
+        elif k.endswith("num_batches_tracked"):
+            assert int(msd[k]) == int(v), k
+    m.masks = None
+    m(x.to(DEV))                                   # Philox masks: runs, updates the statistics once more
+    assert int(m.state_dict()["layer1.1.num_batches_tracked"]) == int(ref_sd["layer1.1.num_batches_tracked"]) + 1
+    m.eval()
+    m.refresh()
+    sd2 = {k: v.cpu() for k, v in m.state_dict().items()}
+    with torch.no_grad():
+        want_eval = O.df_forward(sd2, x)
+    assert (m(x.to(DEV)).cpu() - want_eval).abs().max().item() < 1e-4 * max(1.0, want_eval.abs().max().item())
+
+
+def test_sampler_raises_where_reference_raises():
+    """A saturated length output (sigmoid -> 1.0, index = seq_size) makes the reference's Generator.forward raise IndexError
+    (src/model.py:44); the bulk sampler reports it the same way instead of returning clamped traces."""
+    from wfd_gan_amd.sampler import BulkSampler
+    S, C, Z = 41, 5, 16
+    st = O.make_state(S, C, Z, 0.0, 40.0, seed=1)
+    gsd = {k: v.detach().clone() for k, v in st.G.items()}
+    dmin, dmax = np.zeros(S), np.full(S, 40.0)
+    bs = BulkSampler(gsd, S, C, Z, dmin, dmax, chunk=64, device=DEV, seed=1)
+    labels = (torch.arange(64, device=DEV) % C).to(torch.int32)
+    bs.run_chunk(labels)
+    bs.check_length_index()                        # healthy generator: no error
+    gsd["model.8.bias"][0] = 1e4
+    bad = BulkSampler(gsd, S, C, Z, dmin, dmax, chunk=64, device=DEV, seed=1)
+    bad.run_chunk(labels)
+    with pytest.raises(IndexError):
+        bad.check_length_index()

@@ -354,6 +354,33 @@ __global__ void minmax_transform_kernel(const double* __restrict__ X, long total
     }
 }
 
+// Checkpoint tail (src/mlp_df_wgan_train.py:291-292).  total_real: scaler.inverse_transform(scaler.transform(x)) in
+// float64 -- numpy's four in-place passes X *= scale_; X += min_; X -= min_; X /= scale_, one rounding each.
+__global__ void minmax_roundtrip_kernel(const double* __restrict__ X, long total, int S, const double* __restrict__ scale,
+                                        const double* __restrict__ min_, double* __restrict__ out) {
+    for (long o = (long)blockIdx.x * blockDim.x + threadIdx.x; o < total; o += (long)gridDim.x * blockDim.x) {
+#pragma clang fp contract(off)
+        const int c = (int)(o % S);
+        double t = X[o] * scale[c];
+        t = t + min_[c];
+        t = t - min_[c];
+        out[o] = t / scale[c];
+    }
+}
+// total_fake: scaler.inverse_transform on the float32 generated rows -- X -= min_; X /= scale_ with float64 constants on a
+// float32 array: each pass computes in double and rounds to float32 (the arithmetic of sample_post's first two steps)
+__global__ void minmax_inverse_f32_kernel(const float* __restrict__ Y, int ldy, long M, int S, const double* __restrict__ scale,
+                                          const double* __restrict__ min_, float* __restrict__ out) {
+    const long total = M * S;
+    for (long o = (long)blockIdx.x * blockDim.x + threadIdx.x; o < total; o += (long)gridDim.x * blockDim.x) {
+#pragma clang fp contract(off)
+        const long m = o / S;
+        const int c = (int)(o - m * S);
+        const float t = (float)((double)Y[m * ldy + c] - min_[c]);
+        out[o] = (float)((double)t / scale[c]);
+    }
+}
+
 // ---- burst extraction (src/extract.py:58-122) -------------------------------------------------------------------
 // One workgroup per packet trace (ragged: packets off[i] .. off[i+1] of the concatenated time / size arrays, float64).
 // Long-gap truncation (first / last inter-packet gap > 10 s), skip of the leading incoming packets, then the trace is
@@ -595,6 +622,29 @@ int wfd_minmax_transform_f64(const double* X, long N, int S, const double* scale
     if (blocks > 16384) blocks = 16384;
     hipLaunchKernelGGL(minmax_transform_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, X, total, S, scale,
                        min_, out);
+    WFD_CHECK_LAUNCH();
+    return WFD_OK;
+}
+
+int wfd_minmax_roundtrip_f64(const double* X, long N, int S, const double* scale, const double* min_, double* out,
+                             void* stream) {
+    if (!X || !scale || !min_ || !out || N <= 0 || S <= 0) return WFD_ERR_ARG;
+    const long total = N * S;
+    long blocks = (total + 255) / 256;
+    if (blocks > 16384) blocks = 16384;
+    hipLaunchKernelGGL(minmax_roundtrip_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, X, total, S, scale,
+                       min_, out);
+    WFD_CHECK_LAUNCH();
+    return WFD_OK;
+}
+
+int wfd_minmax_inverse_f32(const float* Y, int ldy, long M, int S, const double* scale, const double* min_, float* out,
+                           void* stream) {
+    if (!Y || !scale || !min_ || !out || M <= 0 || S <= 0 || ldy < S) return WFD_ERR_ARG;
+    long blocks = (M * S + 255) / 256;
+    if (blocks > 16384) blocks = 16384;
+    hipLaunchKernelGGL(minmax_inverse_f32_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, Y, ldy, M, S,
+                       scale, min_, out);
     WFD_CHECK_LAUNCH();
     return WFD_OK;
 }

@@ -106,6 +106,8 @@ class DFTrainEngine:
         nchunk = (B * Ls[0] + self.rpc - 1) // self.rpc
         b["part"] = z(max(nchunk * 2 * 256, ((Ls[0] + 127) // 128) * B * 256))
         b["ws"] = torch.empty(max(workspace_mb * (1 << 18), B * Ls[0] * 64), **f32)
+        self.fwd_plan = Plan(b["ws"])              # DF.forward in train mode alone (module shell, model.DF.forward)
+        self._build_forward(self.fwd_plan)
         self.plan = self._build()
         self.graph = None
 
@@ -162,16 +164,12 @@ class DFTrainEngine:
         return out
 
     # ------------------------------------------------------------------------------------------------------
-    def _build(self) -> Plan:
+    def _build_forward(self, p: Plan):
+        """DF.forward in train mode (src/model.py:198-206): batch statistics, running-stat updates, dropout masks."""
         L, b, P, B, C, Ls, lv = self.L, self.buf, self.P, self.B, self.C, self.Ls, self.lv
-        p = Plan(b["ws"])
-        w, g = P.p, P.g
+        w = P.p
         rpc, part = self.rpc, ptr(b["part"])
-        Z, Y, dA, PO, POd, DPO, MK, WT = b["Z"], b["Y"], b["dA"], b["PO"], b["POd"], b["DPO"], b["MK"], b["WT"]
-        for k in range(1, 7):
-            conv, _bn, cin, cout, _a, _p = DF_CONVS[k]
-            p.add(L.conv_wflip, ptr(w[f"{conv}.conv.weight"]), cout, cin, ptr(WT[k]))
-        # ---- forward (src/model.py:198-206, train mode) ------------------------------------------------------
+        Z, Y, PO, POd, MK = b["Z"], b["Y"], b["PO"], b["POd"], b["MK"]
         cur, pi = None, 0
         for k, (conv, bn, cin, cout, act, pool) in enumerate(DF_CONVS):
             M = B * Ls[lv[k]]
@@ -201,6 +199,18 @@ class DFTrainEngine:
             p.add(L.mul_mask, ptr(b[f"H{i}"]), ptr(MK[3 + i]), B * 512, ptr(b[f"Hd{i}"]))
             prev, kp = b[f"Hd{i}"], 512
         p.gemm_affine(NT, prev, 512, w["fc.weight"], 512, B, C, 512, None, w["fc.bias"], ACT_NONE, b["LOG"], self.ldc)
+
+    def _build(self) -> Plan:
+        L, b, P, B, C, Ls, lv = self.L, self.buf, self.P, self.B, self.C, self.Ls, self.lv
+        p = Plan(b["ws"])
+        w, g = P.p, P.g
+        rpc, part = self.rpc, ptr(b["part"])
+        Z, Y, dA, PO, POd, DPO, MK, WT = b["Z"], b["Y"], b["dA"], b["PO"], b["POd"], b["DPO"], b["MK"], b["WT"]
+        kin = self.kin
+        for k in range(1, 7):
+            conv, _bn, cin, cout, _a, _p = DF_CONVS[k]
+            p.add(L.conv_wflip, ptr(w[f"{conv}.conv.weight"]), cout, cin, ptr(WT[k]))
+        self._build_forward(p)
         # ---- CrossEntropyLoss (mean) and its gradient --------------------------------------------------------
         p.add(L.masked_ce, ptr(b["LOG"]), self.ldc, B, C, ptr(b["labels"]), ptr(b["ones"]), ptr(b["nsel"]), 1.0,
               ptr(b["CE"]), ptr(b["DLOG"]), self.ldc)
@@ -281,8 +291,17 @@ class DFTrainEngine:
                                     self.rng_state.data_ptr(), 0, st)
         self.L.iter_advance(self.rng_state.data_ptr(), (n4 + 3) // 4, 0, st)
 
+    def forward_train(self) -> torch.Tensor:
+        """Forward pass alone in train mode on the batch / masks set before; returns the logits (B, C)."""
+        self.fwd_plan.run()
+        self._count_batch()
+        return self.buf["LOG"][:, : self.C]
+
     def train_step(self):
         self.plan.run()
+        self._count_batch()
+
+    def _count_batch(self):
         for _conv, bn, *_ in DF_CONVS:
             self.nbt[f"{bn}.num_batches_tracked"] = self.nbt.get(f"{bn}.num_batches_tracked", 0) + 1
         for bn in ("layer5.1", "layer5.5"):

@@ -550,7 +550,7 @@ class TrainEngine:
             rows.append([ptr(X), ldx, ptr(rs), ptr(X2), ldx2, ptr(rs2), M, N, ptr(out), blk, ptr(acc)])
             blk += (N + 31) // 32
         desc = torch.tensor(rows, dtype=torch.int64, device=self.dev)
-        self.buf["desc_" + name] = desc
+        p.keep.append(desc)          # owned by the plan: a later rebuild of a D plan must not free what this one points at
         p.add(self.L.colsum_multi, ptr(desc), len(rows), blk)
 
     def _grad_bucket_hook(self, p: Plan, which: str, stage: int):
@@ -892,6 +892,7 @@ class TrainEngine:
                 g = torch.cuda.CUDAGraph()
                 with torch.cuda.graph(g):
                     st.run()
+                g.keep = plan.keep          # the captured launches point into the plan's descriptor tables
                 out.append(g.replay)
             else:
                 out.append(st)
@@ -1142,7 +1143,9 @@ class GroupedTrainer:
         p.add(L.gather_batch_slots, ptr(eng.data_X), S, ptr(eng.data_y), ptr(eng.perm), state, eng.N, eng.N, eng.row_offset,
               B, n, eng.cursor_step, S, C, ptr(real0), ptr(fake0), eng.ldx, slot_stride, ptr(st["ZIN"]), eng.ldz, Z,
               ptr(st["labels"]))
-        p.add(L.rng_normal_rows, ptr(st["ZIN"]), eng.ldz, M, Z, (eng.seed + 7 * eng.GOLD) & (2**64 - 1), state, 0)
+        # its own Philox key: the single-iteration plans (fast_d, key seed + 7 GOLD) count from 0 as well, and the trainer
+        # runs iteration 0 of an epoch on them -- with a shared key iteration 1 would repeat iteration 0's noise
+        p.add(L.rng_normal_rows, ptr(st["ZIN"]), eng.ldz, M, Z, (eng.seed + 13 * eng.GOLD) & (2**64 - 1), state, 0)
         p.gemm_affine(NT, st["ZIN"], eng.ldz, G["model.0.weight"], eng.Gp.ld["model.0.weight"], M, 512, Z + C, None,
                       G["model.0.bias"], ACT_RELU, st["GH1"], 512)
         prev, kprev = st["GH1"], 512

@@ -53,7 +53,16 @@ def parse_args(argv=None):
 class TraceSampler:
     def __init__(self, mdir: str, device="cuda:0", chunk: int = 8192, seed: int = 0, operands: str = "f32",
                  mode: str = "generate"):
-        scaler = joblib.load(join(mdir, "scaler.gz"))          # our own training artefact (sklearn MinMaxScaler)
+        # the fitted MinMaxScaler: model/scaler.npz (data_min_ / data_max_ as plain arrays, written by this package's
+        # trainer next to scaler.gz) is preferred because loading it executes nothing; scaler.gz is the reference's
+        # format (joblib pickle, src/mlp_df_wgan_train.py:312): unpickling runs code from the file, so only point -m at
+        # model directories you trust
+        if os.path.exists(join(mdir, "scaler.npz")):
+            from types import SimpleNamespace
+            with np.load(join(mdir, "scaler.npz"), allow_pickle=False) as f:
+                scaler = SimpleNamespace(data_min_=f["data_min"], data_max_=f["data_max"])
+        else:
+            scaler = joblib.load(join(mdir, "scaler.gz"))
         paths = glob.glob(join(mdir, "generator*.ckpt"))
         assert len(paths) == 1, f"expected exactly one generator checkpoint in {mdir}"
         info = re.match(cm.GENERATOR_NAME_REG, os.path.basename(paths[0]))

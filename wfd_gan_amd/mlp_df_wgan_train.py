@@ -13,7 +13,8 @@ ranks with synchronised BatchNorm statistics and a global selected-row count: th
 ranks hold the dataset and the same epoch permutation; rank 0 writes the artefacts.
 Per iteration nothing leaves the GPU: the dataset is resident in HBM, batches / z / dropout masks are produced on
 device, the D-step and G-step are HIP-graph replays, and the epoch's loss sums accumulate in device memory (the
-reference's 2-5 ``.item()`` syncs and per-G-step D2H copies are gone; one sync per epoch reads the sums).
+reference's 2-5 ``.item()`` syncs and per-G-step D2H copies are gone; per epoch one sync reads the loss sums and one the
+DF-accuracy count).
 """
 import argparse
 import json
@@ -85,17 +86,41 @@ def clip_dataset(X: np.ndarray, device) -> np.ndarray:
 
 def df_accuracy(f_model: DF, fakes: torch.Tensor, labels: torch.Tensor, comm=None) -> float:
     """test_DF_acc_epoch (:57-79): DF argmax accuracy over this epoch's generated traces, batches of 128 (summed
-    over the ranks' shares in data-parallel runs)."""
-    total, correct = 0, 0
-    for a in range(0, fakes.shape[0], 128):
+    over the ranks' shares in data-parallel runs).  The correct-prediction count accumulates in device memory
+    (wfd_argmax_correct: first maximum, as torch.argmax) and is read once."""
+    L = lib()
+    dev = fakes.device
+    correct = torch.zeros(1, dtype=torch.int32, device=dev)
+    lab32 = labels.to(torch.int32).contiguous()
+    total = fakes.shape[0]
+    st = torch.cuda.current_stream(dev).cuda_stream
+    C = f_model.num_classes
+    for a in range(0, total, 128):
         x = fakes[a:a + 128, 1:]
-        pred = f_model(x.reshape(x.shape[0], 1, x.shape[1])).argmax(1)
-        correct += int((pred == labels[a:a + 128]).sum())
-        total += x.shape[0]
+        logits = f_model(x.reshape(x.shape[0], 1, x.shape[1]))
+        L.argmax_correct(logits.data_ptr(), logits.stride(0), x.shape[0], C, lab32[a:a + 128].data_ptr(), correct.data_ptr(), st)
+    n_ok = int(correct.item())
     if comm is not None and comm.world > 1:
-        t = comm.all_reduce_sum_(torch.tensor([correct, total], dtype=torch.float64, device=fakes.device))
-        correct, total = t.tolist()
-    return correct / max(total, 1)
+        t = comm.all_reduce_sum_(torch.tensor([n_ok, total], dtype=torch.float64, device=dev))
+        n_ok, total = t.tolist()
+    return n_ok / max(total, 1)
+
+
+def epoch_dump(scaler, X_rows: np.ndarray, fakes: torch.Tensor):
+    """The two arrays of checkpoint/epoch_N.npz (:288-297) on the device: ``x`` = inverse_transform(transform(real rows)) in
+    float64, ``recon_x`` = inverse_transform(generated rows) in float32 -- bit-identical to sklearn's in-place passes."""
+    L = lib()
+    dev = fakes.device
+    st = torch.cuda.current_stream(dev).cuda_stream
+    sd, md = torch.from_numpy(scaler.scale_.copy()).to(dev), torch.from_numpy(scaler.min_.copy()).to(dev)
+    Xd = torch.from_numpy(np.ascontiguousarray(X_rows, dtype=np.float64)).to(dev)
+    N, S = Xd.shape
+    real = torch.empty_like(Xd)
+    L.minmax_roundtrip_f64(Xd.data_ptr(), N, S, sd.data_ptr(), md.data_ptr(), real.data_ptr(), st)
+    fk = fakes.contiguous()
+    recon = torch.empty(fk.shape[0], S, dtype=torch.float32, device=dev)
+    L.minmax_inverse_f32(fk.data_ptr(), fk.stride(0), fk.shape[0], S, sd.data_ptr(), md.data_ptr(), recon.data_ptr(), st)
+    return real.cpu().numpy(), recon.cpu().numpy()
 
 
 class _Quiet:
@@ -136,6 +161,9 @@ def main(argv=None):
             np.savez_compressed(args.dir.split(".npz")[0] + "_clip.npz", features=X, labels=y)
         logger.info("Save back  the clipped dataset to {}".format(args.dir.split(".npz")[0] + "_clip.npz"))
     y = y - y.min()
+    if int(y.max()) >= len(np.unique(y)):
+        # np.eye(class_dim)[c] (:185) fails the same way on labels that are not 0 .. class_dim - 1 after the shift
+        raise IndexError("index {} is out of bounds for axis 0 with size {}".format(int(y.max()), len(np.unique(y))))
 
     # MinMaxScaler fit + transform + the loop's .float() on the device, once (bit-identical to the host path)
     Xs_dev, scaler = utils.fit_transform_device(X, device)
@@ -255,8 +283,7 @@ def main(argv=None):
                 fake_all = comm.all_gather(fake_all).reshape(-1, seq_len)
             if rank == 0:
                 sel = idx_all.cpu().numpy()
-                total_real = scaler.inverse_transform(scaler.transform(X[sel]))          # float64, as :288
-                total_fake = scaler.inverse_transform(fake_all.cpu().numpy())            # float32
+                total_real, total_fake = epoch_dump(scaler, X[sel], fake_all)            # float64 / float32, as :291-292
                 np.savez_compressed(join(checkpointdir, "epoch_{}".format(epoch + 1)), x=total_real,
                                     recon_x=total_fake, label=y[sel])
         losses["generator"].append(g_ep)
@@ -275,6 +302,8 @@ def main(argv=None):
     torch.save({k: v.cpu() for k, v in eng.discriminator_state().items()}, join(modeldir, "discriminator.ckpt"))
     logger.info("Model saved at {}".format(modeldir))
     joblib.dump(scaler, join(modeldir, "scaler.gz"))
+    # the same fit as plain arrays: generate.py reads this one without unpickling anything
+    np.savez(join(modeldir, "scaler.npz"), data_min=scaler.data_min_, data_max=scaler.data_max_)
     logger.info("Scaler saved at {}".format(modeldir))
     return pardir
 

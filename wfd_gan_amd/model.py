@@ -183,8 +183,14 @@ class Discriminator(nn.Module):
         return bufs["v"].clone().unsqueeze(1)
 
 
+def _channels_last(x: torch.Tensor) -> torch.Tensor:
+    """(B, C, L) -> contiguous [B][L][C] rows, the layout of the conv / pool kernels."""
+    return x.detach().to(torch.float32).permute(0, 2, 1).contiguous()
+
+
 class MyConv1dPadSame(nn.Module):
-    """Parameter holder for the k=8 stride-1 SAME conv (state_dict key ``<name>.conv.*``, src/model.py:75-105)."""
+    """k=8 stride-1 Conv1d with "SAME" zero padding, left 3 / right 4 (src/model.py:75-105; state_dict key
+    ``<name>.conv.*``).  forward runs the HIP conv kernels: (B, Cin, L) -> (B, Cout, L)."""
 
     def __init__(self, in_channels, out_channels, kernel_size, stride):
         super().__init__()
@@ -193,19 +199,59 @@ class MyConv1dPadSame(nn.Module):
         self.in_channels, self.out_channels, self.kernel_size, self.stride = in_channels, out_channels, kernel_size, stride
         self.conv = nn.Conv1d(in_channels, out_channels, kernel_size, stride)
 
+    def forward(self, x):
+        _need_gpu(x, "MyConv1dPadSame.forward")
+        L = lib()
+        B, cin, Ln = x.shape
+        cout, dev = self.out_channels, x.device
+        if cin != self.in_channels:
+            raise RuntimeError(f"expected {self.in_channels} input channels, got {cin}")
+        w, bias = self.conv.weight.detach().float(), self.conv.bias.detach().float().contiguous()
+        out = torch.empty(B * Ln, cout, dtype=torch.float32, device=dev)
+        if cin == 1:
+            xin = x.detach().to(torch.float32).reshape(B, Ln).contiguous()
+            ones = torch.ones(cout, dtype=torch.float32, device=dev)
+            wr = w.reshape(cout, 8).contiguous()
+            L.df_conv1_fwd(xin.data_ptr(), Ln, 0, B, Ln, wr.data_ptr(), ones.data_ptr(), bias.data_ptr(), ACT_NONE,
+                           out.data_ptr(), cout, torch.cuda.current_stream().cuda_stream)
+        elif cin % 4 == 0:
+            xin = _channels_last(x)
+            wp = w.permute(0, 2, 1).reshape(cout, 8 * cin).contiguous()        # [Cout][tap * Cin + ci]
+            p = Plan(_Workspace.get(dev, max(1 << 24, 16 * B * Ln * rup(cout, 4))))
+            p.conv8_affine(xin, B, Ln, cin, 3, wp, cout, None, bias, ACT_NONE, out)
+            p.run()
+        else:
+            raise NotImplementedError("in_channels must be 1 or a multiple of 4 (the DF observer's are 1, 32, 64, 128)")
+        return out.view(B, Ln, cout).permute(0, 2, 1).contiguous()
+
 
 class MyMaxPool1dPadSame(nn.Module):
-    """Zero-pad (3,4) then MaxPool1d(8) with stride 8 (src/model.py:108-132); no parameters."""
+    """Zero-pad (3,4) then MaxPool1d(8) with stride 8 (src/model.py:108-132; the ``stride_size`` argument only enters the
+    reference's padding arithmetic); no parameters.  forward: (B, C, L) -> (B, C, ceil(L / 8))."""
 
     def __init__(self, kernel_size, stride_size):
         super().__init__()
+        if kernel_size != 8 or stride_size != 1:
+            raise NotImplementedError("the DF observer pools with kernel_size=8, stride_size=1 everywhere")
         self.kernel_size, self.stride = kernel_size, stride_size
+
+    def forward(self, x):
+        _need_gpu(x, "MyMaxPool1dPadSame.forward")
+        B, C, Ln = x.shape
+        xin = _channels_last(x)
+        Lo = (Ln + 7) // 8
+        out = torch.empty(B * Lo, C, dtype=torch.float32, device=x.device)
+        lib().df_pool8_fwd(xin.data_ptr(), B, Ln, C, out.data_ptr(), torch.cuda.current_stream().cuda_stream)
+        return out.view(B, Lo, C).permute(0, 2, 1).contiguous()
 
 
 class DF(nn.Module):
-    """Deep-Fingerprinting observer, 7 convs + 3 FC (src/model.py:135-212).  forward = eval-mode inference on the
-    HIP kernels (BN from running statistics, dropout off), which is how the GAN trainer uses it
-    (src/mlp_df_wgan_train.py:155).  Training the observer itself (train_df.py) is outside this path."""
+    """Deep-Fingerprinting observer, 7 convs + 3 FC (src/model.py:135-212).  In eval mode forward is inference on the
+    frozen observer (BN from running statistics, dropout off), which is how the GAN trainer uses it
+    (src/mlp_df_wgan_train.py:155).  In train mode forward is the reference's train-mode pass (BatchNorm on batch
+    statistics with running-stat updates, dropout masks from Philox on device -- or the masks in ``self.masks`` when a
+    test sets them) on the kernels of df_engine.DFTrainEngine; like the other shells it builds no autograd graph: the
+    observer's training step (forward + backward + Adamax, src/train_df.py:121-131) is DFTrainEngine.train_step."""
 
     def __init__(self, length, num_classes=100):
         super().__init__()
@@ -232,17 +278,43 @@ class DF(nn.Module):
             res = int(math.ceil(res / 8))
         return res
 
+    def _forward_train(self, x):
+        from .df_engine import DFTrainEngine
+        B, dev = x.shape[0], x.device
+        key = ("train", B, dev)
+        eng = self._cache.get(key)
+        if eng is None:
+            eng = self._cache[key] = DFTrainEngine(self.length, self.num_classes, B, self.state_dict(), device=dev,
+                                                   seed=0xD0F, workspace_mb=64)
+        else:
+            eng.load(self.state_dict())              # parameters / running statistics may have changed since
+        eng.set_batch(x.reshape(B, self.length), torch.zeros(B, dtype=torch.int64))
+        masks = getattr(self, "masks", None)
+        if masks is not None:
+            eng.set_masks(masks)
+        else:
+            eng.draw_masks()
+        logits = eng.forward_train().clone()
+        with torch.no_grad():                        # what nn.BatchNorm1d leaves behind after a train-mode forward
+            for k, v in self.state_dict().items():
+                if k.endswith("running_mean") or k.endswith("running_var"):
+                    v.copy_(eng.bufs[k])
+                elif k.endswith("num_batches_tracked"):
+                    v += 1
+        return logits
+
     def forward(self, x):
         _need_gpu(x, "DF.forward")
         if self.training:
-            raise NotImplementedError("DF.forward runs the frozen (eval-mode) observer only; call .eval() first "
-                                      "as src/mlp_df_wgan_train.py:155 does")
+            return self._forward_train(x)
         B = x.shape[0]
         dev = x.device
         key = (B, self.fc.weight.data_ptr(), dev)
         ent = self._cache.get(key)
         if ent is None:
-            self._cache.clear()
+            # one packed observer + buffer set per batch size (the accuracy pass alternates 128-row and remainder batches)
+            for k in [k for k in self._cache if k[1] != key[1] or k[0] == "train"]:
+                del self._cache[k]
             df = ObserverDF(self.state_dict(), self.length, self.num_classes, dev)
             ob = observer_buffers(df, B, dev)
             xin = torch.zeros(B, rup(self.length, 4), dtype=torch.float32, device=dev)

@@ -57,6 +57,9 @@ class Plan:
         self.two = side_workspace is not None          # side lane available (own slab workspace)
         self.ws_lane = [workspace, side_workspace if self.two else workspace]
         self.calls: List[Tuple] = []
+        # device tensors that only this plan's launches reference by raw pointer (descriptor tables): they live as long as
+        # the plan (and any plan it is concatenated into, and the graphs captured from it, which keep the plan alive)
+        self.keep: List[torch.Tensor] = []
         self.lane = 0
         self.overlap = self.two and overlap            # side lane on its own stream (else: same stream, in order)
 
@@ -79,6 +82,7 @@ class Plan:
         if other.gemm_mode != self.gemm_mode:
             raise ValueError("plans of different gemm modes cannot be concatenated")
         self.calls += other.calls
+        self.keep += other.keep
 
     def host(self, thunk):
         """A host-side action between launches (a collective): splits the plan into separately captured stages."""
@@ -144,12 +148,14 @@ class Plan:
         """[Plan | thunk, ...]: maximal runs of launches separated by host actions."""
         mk = lambda: Plan(self.ws_lane[0], self.ws_lane[1] if self.two else None, self.overlap, self.gemm_mode, self.wk)
         out, cur = [], mk()
+        cur.keep = self.keep
         for fn, a, lane in self.calls:
             if fn is HOST:
                 if len(cur):
                     out.append(cur)
                 out.append(a[0])
                 cur = mk()
+                cur.keep = self.keep
             else:
                 cur.calls.append((fn, a, lane))
         if len(cur):

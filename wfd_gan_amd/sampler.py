@@ -155,8 +155,16 @@ class BulkSampler:
             self.zin[:, : self.Z].copy_(z.to(self.dev, torch.float32))
         self.plan.run()
 
+    def check_length_index(self):
+        """Host sync: raise what the reference's Generator.forward raises when a row's length output saturates
+        (trunc(y0 * range + min) + 1 >= seq_size: IndexError at src/model.py:44); the kernel clamps the index and sets a flag."""
+        if int(self.err.item()) != 0:
+            self.err.zero_()
+            raise IndexError("index out of bounds in the generator's burst-length mask (model.py:44 semantics)")
+
     def generate(self, labels, z: Optional[torch.Tensor] = None):
-        """Any number of rows: returns (ints (n,S) int32 on device, lens (n,) int32).  Pads the last chunk."""
+        """Any number of rows: returns (ints (n,S) int32 on device, lens (n,) int32).  Pads the last chunk.  Raises
+        IndexError (once, after the last chunk) if any row's length index left the trace, as the reference would."""
         labels = torch.as_tensor(labels)
         n = labels.numel()
         outs, lens = [], []
@@ -171,4 +179,5 @@ class BulkSampler:
             self.run_chunk(lab.to(self.dev), zz)
             outs.append(self.out[:m].clone())
             lens.append(self.lens[:m].clone())
+        self.check_length_index()
         return torch.cat(outs), torch.cat(lens)

@@ -69,6 +69,9 @@ def main(argv=None):
     logger.info("Loaded dataset:{}, min burst:{} max burst:{}, min label:{}, max label:{}"
                 .format(X.shape, X[:, 1:].min(), X[:, 1:].max(), y.min(), y.max()))
     y = y - y.min()
+    if int(y.max()) >= len(np.unique(y)):
+        raise IndexError("labels must be 0 .. num_classes - 1 after the shift by their minimum (got max {} for {} classes)"
+                         .format(int(y.max()), len(np.unique(y))))
     X = preprocessing.MinMaxScaler().fit_transform(X)
     class_dim = len(np.unique(y))
     X = X[:, 1:]                       # the burst count is not a DF feature (src/train_df.py:77-80)
