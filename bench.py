@@ -67,7 +67,7 @@ def build_engine(args, rank, world, device):
     eng = TrainEngine(S, C, Z, B, float(dmin[0]), float(dmax[0]), G.state_dict(), D.state_dict(), F.state_dict(),
                       lr=2e-4, alpha=0.02, n_critic=3, penalty=args.penalty, device=device, seed=1234 + rank,
                       process_group=pg, world_size=world, overlap=bool(args.overlap), rank=rank, sync_bn=strong,
-                      operands=args.operands, wk=bool(args.wk))
+                      operands=args.operands, wk=bool(args.wk), fuse_opt={"0": False, "1": True}.get(args.fuse_opt, args.fuse_opt))
     eng.attach_dataset(Xs, y, shuffle_seed=0 if strong else rank)
     return eng, (dmin.double().cpu().numpy(), dmax.double().cpu().numpy())
 
@@ -104,7 +104,8 @@ def gemm_roofline(eng, plans=None, rep=16, rounds=3):
     from wfd_gan_amd.plan import FORK, HOST, JOIN
     L = eng.L
     gemm_fns = {L.gemm_f32: "gemm", L.conv8_gemm_f32: "conv", L.gemm_f32_fused: "gemm_fused",
-                L.conv8_gemm_f32_fused: "conv", L.gemm_f32_pair: "pair", L.gemm_f32_wk: "gemm_wk", L.conv8_f32_wk: "conv"}
+                L.conv8_gemm_f32_fused: "conv", L.gemm_f32_pair: "pair", L.gemm_f32_wk: "gemm_wk", L.conv8_f32_wk: "conv",
+                L.gemm_f32_rmsprop: "gemm_rms"}
     calls = []
     for plan, weight in (plans or ((eng.fast_d, eng.n_critic), (eng.fast_g, 1))):
         for fn, a, _lane in plan.calls:
@@ -120,7 +121,7 @@ def gemm_roofline(eng, plans=None, rep=16, rounds=3):
                 M, N, K = a[8], a[9], a[10]
             elif kind == "gemm_fused":
                 M, N, K = a[7], a[8], a[9]
-            elif kind == "gemm_wk":
+            elif kind in ("gemm_wk", "gemm_rms"):
                 M, N, K = a[5], a[6], a[7]
             else:
                 M, N, K = a[1] * a[2], a[6], 8 * a[3]
@@ -220,6 +221,9 @@ def main():
     ap.add_argument("--wk", type=int, default=1,
                     help="1: small-batch products with the K split inside the workgroup and the consumer fused into the "
                          "store (gemm_wk.hip); 0: split-K slabs + consumer launches everywhere")
+    ap.add_argument("--fuse-opt", dest="fuse_opt", default="1", choices=["0", "1", "d", "g"],
+                    help="1 (single GPU): RMSprop applied inside each weight gradient's store (wfd_gemm_f32_rmsprop), the "
+                         "gradient never written; 0: gradient buffers + one flat optimizer pass (what data parallel runs)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-sampling", action="store_true")
     ap.add_argument("--no-modes", action="store_true", help="skip the bf16x3 / bf16 operand-mode runs of the same step")
@@ -393,7 +397,8 @@ def main():
                        "samples_per_s": steps_per_s * eng.B * world,
                        "parallelism": f"dp{world}", "graphs": not args.no_graph, "pipelined": pipelined,
                        "grouped_generator_forwards": grouped, "length_index_saturated": saturated,
-                       "operands": args.operands, "wk_fused_products": bool(args.wk)},
+                       "operands": args.operands, "wk_fused_products": bool(args.wk),
+                       "optimizer_in_gradient_store": {"critic": bool(eng.fuse_d), "generator": bool(eng.fuse_g)}},
             "roofline": {"bound": "mfma", "achieved": roof["tflops"], "peak": peak, "unit": "TFLOP/s",
                          "frac": roof["tflops"] / peak, "traffic": traffic if args.operands == "f32" else None,
                          "traffic_note": "bytes/launch, rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command "

@@ -161,6 +161,21 @@ int wfd_colsum_multi(const long long* desc, int nseg, int total_blocks, void* st
 int wfd_rmsprop(float* p, const float* g, float* sq, long n, float lr, float alpha, float eps, float gscale,
                 unsigned long long* state, unsigned long long inc0, unsigned long long inc1, void* stream);
 
+/* The same update on up to 8 element ranges [ranges[2k], ranges[2k+1]) (HOST array) of the flat buffers: the vectors
+ * (biases, BatchNorm affine, the critic's head) of a network whose weight matrices were updated inside their
+ * gradient's store by wfd_gemm_f32_rmsprop.  Bookkeeping as wfd_rmsprop. */
+int wfd_rmsprop_ranges(float* p, const float* g, float* sq, const long* ranges, int nranges, float lr, float alpha, float eps,
+                       unsigned long long* state, unsigned long long inc0, unsigned long long inc1, void* stream);
+
+/* loss.backward() + optimizer.step() for ONE weight matrix (src/mlp_df_wgan_train.py:229-230, 273-275): the gradient
+ * g = (M,N,K) product of the given layout (2 = TN: dW = dZ^T H over the batch rows) is consumed in the store,
+ * SQ = alpha SQ + (1-alpha) g^2;  P -= lr g / (sqrt(SQ) + eps)  (torch.optim.RMSprop defaults), on the parameter
+ * matrix P[M][ldp] and its square average SQ of the same layout; the gradient never reaches memory.  Same bits as
+ * wfd_gemm_f32 into a gradient buffer followed by wfd_rmsprop.  Unsplit contraction (K = rows of the batch);
+ * single-GPU path (data parallel all-reduces the gradient first). */
+int wfd_gemm_f32_rmsprop(int layout, const float* A, int lda, const float* B, int ldb, int M, int N, int K, float* P,
+                         int ldp, float* SQ, float lr, float alpha, float eps, void* stream);
+
 /* nn.BatchNorm1d(n, eps=0.8) training forward (src/model.py:23), in two halves so that data-parallel ranks can
  * combine (mean, M2) in between: stats writes Z = sumP + bias and the per-column mean / sum of squared deviations;
  * apply writes xhat, relu(gamma*xhat+beta), invstd and updates running_mean / running_var (unbiased) nupd times.

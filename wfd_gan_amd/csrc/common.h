@@ -25,6 +25,17 @@ __device__ __forceinline__ float elu_expm1(float v) {
     return v > -0.25f ? p : __expf(v) - 1.f;
 }
 
+// torch.optim.RMSprop defaults (no momentum, not centered, weight decay 0; src/mlp_df_wgan_train.py:163-164): one element.
+// Contraction is switched off inside (every operation rounded on its own, as torch's CPU kernels do), so that every kernel
+// that applies the update -- the flat optimizer pass and the weight-gradient stores that fold it in -- produces the same bits
+// from the same (p, sq, g) whatever the surrounding code looks like.
+__device__ __forceinline__ void rmsprop_update(float& p, float& s, float g, float lr, float alpha, float eps) {
+#pragma clang fp contract(off)
+    const float t = (1.f - alpha) * g * g;
+    s = s * alpha + t;
+    p = p - lr * g / (sqrtf(s) + eps);
+}
+
 static inline int cdiv(long a, long b) { return (int)((a + b - 1) / b); }
 
 __device__ __forceinline__ float wave_sum(float v) {

@@ -358,25 +358,42 @@ __global__ void rmsprop_kernel(float* __restrict__ p, const float* __restrict__ 
             float4 gv = *reinterpret_cast<const float4*>(g + i);
             float4 sv = *reinterpret_cast<const float4*>(sq + i);
             float4 pv = *reinterpret_cast<const float4*>(p + i);
-            gv.x *= gscale; gv.y *= gscale; gv.z *= gscale; gv.w *= gscale;
-            sv.x = sv.x * alpha + (1.f - alpha) * gv.x * gv.x;
-            sv.y = sv.y * alpha + (1.f - alpha) * gv.y * gv.y;
-            sv.z = sv.z * alpha + (1.f - alpha) * gv.z * gv.z;
-            sv.w = sv.w * alpha + (1.f - alpha) * gv.w * gv.w;
-            pv.x -= lr * gv.x / (sqrtf(sv.x) + eps);
-            pv.y -= lr * gv.y / (sqrtf(sv.y) + eps);
-            pv.z -= lr * gv.z / (sqrtf(sv.z) + eps);
-            pv.w -= lr * gv.w / (sqrtf(sv.w) + eps);
+            rmsprop_update(pv.x, sv.x, gv.x * gscale, lr, alpha, eps);
+            rmsprop_update(pv.y, sv.y, gv.y * gscale, lr, alpha, eps);
+            rmsprop_update(pv.z, sv.z, gv.z * gscale, lr, alpha, eps);
+            rmsprop_update(pv.w, sv.w, gv.w * gscale, lr, alpha, eps);
             *reinterpret_cast<float4*>(sq + i) = sv;
             *reinterpret_cast<float4*>(p + i) = pv;
         } else {
             for (long j = i; j < n; ++j) {
-                const float gg = g[j] * gscale;
-                const float s = sq[j] * alpha + (1.f - alpha) * gg * gg;
-                sq[j] = s;
-                p[j] -= lr * gg / (sqrtf(s) + eps);
+                float pj = p[j], sj = sq[j];
+                rmsprop_update(pj, sj, g[j] * gscale, lr, alpha, eps);
+                sq[j] = sj;
+                p[j] = pj;
             }
         }
+    }
+}
+
+// The same update on up to 8 element ranges [beg, end) of the flat buffers: the vectors (biases, BatchNorm affine, the
+// critic's head) of a network whose weight matrices were updated in their gradient's store (wfd_gemm_f32_rmsprop).
+struct RmsRanges { long beg[8], end[8]; int n; };
+__global__ void rmsprop_ranges_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ sq, RmsRanges r,
+                                      float lr, float alpha, float eps, unsigned long long* __restrict__ state,
+                                      unsigned long long inc0, unsigned long long inc1) {
+    if (state && blockIdx.x == 0 && threadIdx.x == 0) { state[0] += inc0; state[1] += inc1; }
+    long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    for (int k = 0; k < r.n; ++k) {
+        const long len = r.end[k] - r.beg[k];
+        if (i < len) {
+            const long j = r.beg[k] + i;
+            float pj = p[j], sj = sq[j];
+            rmsprop_update(pj, sj, g[j], lr, alpha, eps);
+            sq[j] = sj;
+            p[j] = pj;
+            return;
+        }
+        i -= len;
     }
 }
 
@@ -1022,6 +1039,24 @@ int wfd_rmsprop(float* p, const float* g, float* sq, long n, float lr, float alp
     if (blocks < 1) blocks = 1;
     hipLaunchKernelGGL(rmsprop_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, p, g, sq, n, lr, alpha,
                        eps, gscale, state, inc0, inc1);
+    WFD_CHECK_LAUNCH();
+    return WFD_OK;
+}
+
+int wfd_rmsprop_ranges(float* p, const float* g, float* sq, const long* ranges, int nranges, float lr, float alpha, float eps,
+                       unsigned long long* state, unsigned long long inc0, unsigned long long inc1, void* stream) {
+    if (!p || !g || !sq || !ranges || nranges < 1 || nranges > 8) return WFD_ERR_ARG;
+    RmsRanges r{};
+    long total = 0;
+    for (int k = 0; k < nranges; ++k) {
+        r.beg[k] = ranges[2 * k]; r.end[k] = ranges[2 * k + 1];
+        if (r.beg[k] < 0 || r.end[k] < r.beg[k]) return WFD_ERR_ARG;
+        total += r.end[k] - r.beg[k];
+    }
+    r.n = nranges;
+    if (total <= 0) return WFD_ERR_ARG;
+    hipLaunchKernelGGL(rmsprop_ranges_kernel, dim3(cdiv(total, 256)), dim3(256), 0, (hipStream_t)stream, p, g, sq, r, lr, alpha,
+                       eps, state, inc0, inc1);
     WFD_CHECK_LAUNCH();
     return WFD_OK;
 }

@@ -207,7 +207,10 @@ __device__ __forceinline__ f32x4 read_frag(const float* __restrict__ S, int row0
 
 // NARROW / EPI are compile-time so that the plain path keeps its instruction schedule (a runtime branch inside the
 // k-loop made hipcc stop hoisting the next tile's global loads above the MFMA block).
-template <bool AKC, bool BKC, int VA, int VB, bool IM2COL, bool NARROW, bool EPI>
+// EPI: 0 raw slabs; 1 fused store (epi_store); 2 RMSprop in the store with the parameter / square-average tile PREFETCHED
+// into registers right after the first k-tile, so that their 2 x 16 loads per lane land during the k-loop instead of
+// stalling the store (the store then only adds the second write stream).
+template <bool AKC, bool BKC, int VA, int VB, bool IM2COL, bool NARROW, int EPI>
 __device__ __forceinline__ void gemm_f32_body(const GemmArgs& g, float* __restrict__ lds, int bx, int by, int bz) {
     // lds: 4 * TILE_F floats; buffer c: A tile at lds + 2c*TILE_F, B tile right behind it
 
@@ -254,10 +257,22 @@ __device__ __forceinline__ void gemm_f32_body(const GemmArgs& g, float* __restri
     }
     __syncthreads();
     WFD_STAMP(1)
+    float pp[16], sv[16];
+    auto prefetch_params = [&]() {
+        // issued AFTER the last operand tile's loads: loads retire in order, so a prefetch issued earlier would sit in front
+        // of every tile the k-loop still waits for
+        const int pcol = min(n0 + bcol0 + i, g.N - 1);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int prow = min(m0 + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * h, g.M - 1);
+            pp[r] = g.P[(long)prow * g.ldp + pcol];
+            sv[r] = g.sq[(long)prow * g.ldp + pcol];
+        }
+    };
     int cur = 0;
-    for (int kt = 0; kt < nk; ++kt) {
-        const bool more = kt + 1 < nk;
+    auto step = [&](int kt, bool more, bool pf) {
         if (more) load_both(kt + 1);
+        if constexpr (EPI == 2) { if (pf) prefetch_params(); }
         const float* a_s = lds + cur * 2 * TILE_F;
         const float* b_s = a_s + TILE_F;
         if constexpr (!NARROW) {
@@ -283,6 +298,16 @@ __device__ __forceinline__ void gemm_f32_body(const GemmArgs& g, float* __restri
         }
         __syncthreads();
         cur ^= 1;
+    };
+    if constexpr (EPI == 2) {
+        // peeled: the parameter / square-average tile is requested right behind the loads of the LAST operand tile, so it
+        // lands during the last two tiles' MFMA blocks (and the other resident workgroups' loops)
+        for (int kt = 0; kt + 2 < nk; ++kt) step(kt, true, false);
+        if (nk >= 2) step(nk - 2, true, true);
+        if (nk < 2) prefetch_params();
+        if (nk >= 1) step(nk - 1, false, false);
+    } else {
+        for (int kt = 0; kt < nk; ++kt) step(kt, kt + 1 < nk, false);
     }
 
     WFD_STAMP(2)
@@ -306,8 +331,15 @@ __device__ __forceinline__ void gemm_f32_body(const GemmArgs& g, float* __restri
         for (int r = 0; r < 16; ++r) {
             const int row = m0 + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
             if (row < g.M) {
-                if constexpr (EPI) P[(long)row * g.ldp + col] = epi_apply(g, acc[r], row, col);
-                else P[(long)row * g.ldp + col] = acc[r];
+                if constexpr (EPI == 2) {
+                    rmsprop_update(pp[r], sv[r], acc[r], g.lr, g.alpha, g.eps);
+                    g.sq[(long)row * g.ldp + col] = sv[r];
+                    P[(long)row * g.ldp + col] = pp[r];
+                } else if constexpr (EPI == 1) {
+                    epi_store(g, P, acc[r], row, col);
+                } else {
+                    P[(long)row * g.ldp + col] = acc[r];
+                }
             }
         }
     }
@@ -326,7 +358,7 @@ extern "C" int wfd_gemm_f32_stamped(int layout, const float* A, int lda, const f
 namespace {
 #endif
 
-template <bool AKC, bool BKC, int VA, int VB, bool IM2COL, bool NARROW, bool EPI>
+template <bool AKC, bool BKC, int VA, int VB, bool IM2COL, bool NARROW, int EPI>
 __global__ __launch_bounds__(NTHREADS) void gemm_f32_kernel(GemmArgs g) {
     __shared__ __attribute__((aligned(16))) float lds[4 * TILE_F];
     gemm_f32_body<AKC, BKC, VA, VB, IM2COL, NARROW, EPI>(g, lds, blockIdx.x, blockIdx.y, blockIdx.z);
@@ -347,14 +379,14 @@ __global__ __launch_bounds__(NTHREADS) void gemm_f32_pair_kernel(GemmArgs g1, Ge
     const int before = (int)((long)id * d.nb2 / tot), upto = (int)((long)(id + 1) * d.nb2 / tot);
     if (upto > before) {                   // wave-uniform: this block belongs to problem 2
         const int j = before, per = d.gx2 * d.gy2;
-        gemm_f32_body<A2KC, B2KC, 4, 4, false, false, false>(g2, lds, (j % per) % d.gx2, (j % per) / d.gx2, j / per);
+        gemm_f32_body<A2KC, B2KC, 4, 4, false, false, 0>(g2, lds, (j % per) % d.gx2, (j % per) / d.gx2, j / per);
     } else {
         const int j = id - before, per = d.gx1 * d.gy1;
-        gemm_f32_body<A1KC, B1KC, 4, 4, false, false, false>(g1, lds, (j % per) % d.gx1, (j % per) / d.gx1, j / per);
+        gemm_f32_body<A1KC, B1KC, 4, 4, false, false, 0>(g1, lds, (j % per) % d.gx1, (j % per) / d.gx1, j / per);
     }
 }
 
-template <bool AKC, bool BKC, bool IM2COL, bool NARROW, bool EPI>
+template <bool AKC, bool BKC, bool IM2COL, bool NARROW, int EPI>
 int launch_gemm2(const GemmArgs& g, int splits, bool va4, bool vb4, hipStream_t st) {
     dim3 grid(NARROW ? cdiv(g.N, 32) : cdiv(g.N, BN), cdiv(g.M, BM), splits), block(NTHREADS);
     if (va4 && vb4) hipLaunchKernelGGL((gemm_f32_kernel<AKC, BKC, 4, 4, IM2COL, NARROW, EPI>), grid, block, 0, st, g);
@@ -441,7 +473,7 @@ __global__ __launch_bounds__(NTHREADS) void conv8_c32_kernel(GemmArgs g, int cpw
             for (int r = 0; r < 16; ++r) {
                 const int row = m0 + wave * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
                 if (row < g.M) {
-                    if constexpr (EPI) g.P[(long)row * g.ldp + col] = epi_apply(g, acc[r], row, col);
+                    if constexpr (EPI) epi_store(g, g.P, acc[r], row, col);
                     else g.P[(long)row * g.ldp + col] = acc[r];
                 }
             }
@@ -572,7 +604,7 @@ __global__ __launch_bounds__(NTHREADS) void gemm_f32_nt128_kernel(GemmArgs g, in
             for (int r = 0; r < 16; ++r) {
                 const int row = m0 + wm * 64 + 32 * a + (r & 3) + 8 * (r >> 2) + 4 * h;
                 if (row >= g.M) continue;
-                if constexpr (EPI) g.P[(long)row * g.ldp + col] = epi_apply(g, acc[a][b][r], row, col);
+                if constexpr (EPI) epi_store(g, g.P, acc[a][b][r], row, col);
                 else g.P[(long)row * g.ldp + col] = acc[a][b][r];
             }
         }
@@ -792,6 +824,39 @@ int wfd_gemm_f32_fused(int layout, const float* A, int lda, const float* B, int 
             if (lda < K || ldb < K) return WFD_ERR_ARG;
             if (use_nt128(M, N, K, va4, vb4)) return launch_nt128<true>(g, st);
             return launch_gemm<true, true, false>(g, 1, va4, vb4, st);
+        case 1: if (lda < K || ldb < N) return WFD_ERR_ARG; return launch_gemm<true, false, false>(g, 1, va4, vb4, st);
+        case 2: if (lda < M || ldb < N) return WFD_ERR_ARG; return launch_gemm<false, false, false>(g, 1, va4, vb4, st);
+        default: return WFD_ERR_ARG;
+    }
+}
+
+// A weight gradient that never reaches memory: g = the (M, N, K) product of the given layout (2 = TN for dW = dZ^T H), and in
+// the store  sq = alpha sq + (1 - alpha) g^2;  P -= lr g / (sqrt(sq) + eps)  on the parameter matrix P[M][ldp] and its
+// square average SQ (same layout) -- loss.backward() + optimizer.step() for one weight matrix
+// (src/mlp_df_wgan_train.py:229-230, 273-275; torch.optim.RMSprop defaults).  Same bits as wfd_gemm_f32 into a gradient
+// buffer followed by wfd_rmsprop.  Single-GPU path only (data parallel must all-reduce the gradient first).  One split:
+// the caller uses it for contractions short enough to go unsplit (K = rows of the batch).
+int wfd_gemm_f32_rmsprop(int layout, const float* A, int lda, const float* B, int ldb, int M, int N, int K, float* P,
+                         int ldp, float* SQ, float lr, float alpha, float eps, void* stream) {
+    if (!A || !B || !P || !SQ || M <= 0 || N <= 0 || K <= 0 || ldp < N) return WFD_ERR_ARG;
+    if (!operands_fit(layout, M, N, K, lda, ldb)) return WFD_ERR_ARG;
+    GemmArgs g{};
+    g.A = A; g.B = B; g.P = P; g.M = M; g.N = N; g.K = K; g.lda = lda; g.ldb = ldb; g.ldp = ldp;
+    g.ktiles_per_split = cdiv(K, BK);
+    g.narrow = N <= 32;
+    g.epi = 4; g.sq = SQ; g.lr = lr; g.alpha = alpha; g.eps = eps;
+    hipStream_t st = (hipStream_t)stream;
+    const bool va4 = aligned16(A) && (lda % 4 == 0), vb4 = aligned16(B) && (ldb % 4 == 0);
+    if (g_gemm_mode && va4 && vb4 && layout >= 0 && layout <= 2) {
+        if (layout == 2 ? (lda < M || ldb < N) : (lda < K || ldb < (layout == 0 ? K : N))) return WFD_ERR_ARG;
+        return wfd_mx_launch(g, layout, 1, g_gemm_mode, st);
+    }
+    if (layout == 2 && va4 && vb4 && !g.narrow) {        // the form the training step runs: tile prefetched during the k-loop
+        if (lda < M || ldb < N) return WFD_ERR_ARG;
+        return launch_gemm2<false, false, false, false, 2>(g, 1, true, true, st);
+    }
+    switch (layout) {
+        case 0: if (lda < K || ldb < K) return WFD_ERR_ARG; return launch_gemm<true, true, false>(g, 1, va4, vb4, st);
         case 1: if (lda < K || ldb < N) return WFD_ERR_ARG; return launch_gemm<true, false, false>(g, 1, va4, vb4, st);
         case 2: if (lda < M || ldb < N) return WFD_ERR_ARG; return launch_gemm<false, false, false>(g, 1, va4, vb4, st);
         default: return WFD_ERR_ARG;

@@ -13,11 +13,15 @@ struct GemmArgs {
     int ktiles_per_split;
     int convL, convCin, convPad;  // IM2COL only
     int narrow;                   // N <= 32: the two wave columns split each k-tile instead of the N range
-    // fused epilogue (splits == 1 only): 0 raw; 1 out = act(acc*scale[n]+shift[n]); 2 out = acc*f(D[m][n])*scale[n]
+    // fused epilogue (splits == 1 only): 0 raw; 1 out = act(acc*scale[n]+shift[n]); 2 out = acc*f(D[m][n])*scale[n];
+    // 4: the product is a weight gradient and P the parameter matrix itself: RMSprop in the store (P, sq updated in place,
+    //    the gradient never reaches memory)
     int epi, act, dmode, ldd;
     const float* scale;
     const float* shift;
     const float* D;
+    float* sq;
+    float lr, alpha, eps;
 };
 
 static __device__ __forceinline__ float epi_apply(const GemmArgs& g, float v, int row, int col) {
@@ -37,4 +41,17 @@ static __device__ __forceinline__ float epi_apply(const GemmArgs& g, float v, in
         if (g.scale) v *= g.scale[col];
     }
     return v;
+}
+
+// the store of a fused launch: element (row, col) of the product
+static __device__ __forceinline__ void epi_store(const GemmArgs& g, float* __restrict__ P, float v, int row, int col) {
+    const long idx = (long)row * g.ldp + col;
+    if (g.epi == 4) {
+        float p = P[idx], s = g.sq[idx];
+        rmsprop_update(p, s, v, g.lr, g.alpha, g.eps);
+        g.sq[idx] = s;
+        P[idx] = p;
+    } else {
+        P[idx] = epi_apply(g, v, row, col);
+    }
 }

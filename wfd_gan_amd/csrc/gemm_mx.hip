@@ -280,7 +280,7 @@ __global__ __launch_bounds__(XT) void gemm_mx_kernel(GemmArgs g, int kchunk, int
             for (int r = 0; r < 16; ++r) {
                 const int row = m0 + wm * (T / 2) + 32 * a + (r & 3) + 8 * (r >> 2) + 4 * h;
                 if (row >= g.M) continue;
-                if constexpr (EPI) P[(long)row * g.ldp + col] = epi_apply(g, acc[a][b][r], row, col);
+                if constexpr (EPI) epi_store(g, P, acc[a][b][r], row, col);
                 else P[(long)row * g.ldp + col] = acc[a][b][r];
             }
         }
@@ -465,7 +465,7 @@ __global__ __launch_bounds__(XT) void conv8_lds_mx_kernel(GemmArgs g, int cpw, i
                 for (int r = 0; r < 16; ++r) {
                     const int row = m0 + wave * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
                     if (row < g.M) {
-                        if constexpr (EPI) g.P[(long)row * g.ldp + col] = epi_apply(g, acc[b][r], row, col);
+                        if constexpr (EPI) epi_store(g, g.P, acc[b][r], row, col);
                         else g.P[(long)row * g.ldp + col] = acc[b][r];
                     }
                 }

@@ -70,6 +70,22 @@ class FlatParams:
         self.sq = torch.zeros(off, dtype=torch.float32, device=device)
         self.p = {n: self._view(self.flat, n, s) for n, s in specs}
         self.g = {n: self._view(self.grad, n, s) for n, s in specs}
+        self.s = {n: self._view(self.sq, n, s) for n, s in specs}
+
+    def vector_ranges(self):
+        """Element ranges [(begin, end)] of the flat buffer that hold no weight matrix (biases, BatchNorm affine, the
+        critic's head), maximal runs in storage order."""
+        out, start = [], None
+        for name, shape in self.specs:
+            if len(shape) == 2 and shape[0] > 1:
+                if start is not None:
+                    out.append((start, self.offsets[name]))
+                    start = None
+            elif start is None:
+                start = self.offsets[name]
+        if start is not None:
+            out.append((start, self.numel))
+        return out
 
     def _view(self, flat: torch.Tensor, name: str, shape):
         o, ld = self.offsets[name], self.ld[name]
@@ -169,7 +185,7 @@ class TrainEngine:
                  seed: int = 0, workspace_mb: int = 256, process_group=None, world_size: int = 1,
                  share: Optional["TrainEngine"] = None, overlap: bool = False, force_sync: bool = False,
                  sync_bn: bool = False, rank: int = 0, stacked: Optional[Dict[str, torch.Tensor]] = None,
-                 slot: int = 0, operands: str = "f32", pair: bool = True, wk: bool = True):
+                 slot: int = 0, operands: str = "f32", pair: bool = True, wk: bool = True, fuse_opt: bool = False):
         """Data parallel, two modes:
           * sync_bn=False (weak scaling, DDP semantics): every rank trains on its own ``batch`` rows with local
             BatchNorm statistics and a local selected-row count; gradients are averaged over ranks.
@@ -191,6 +207,11 @@ class TrainEngine:
         self.pair = bool(pair) and not overlap
         # wk: small-batch products with the K split inside the workgroup and the consumer fused into the store (gemm_wk.hip)
         self.wk = bool(wk)
+        # fuse_opt (single-GPU path): every weight matrix is updated inside its gradient's store (wfd_gemm_f32_rmsprop: the
+        # gradient is never written or read back), the vectors by one small wfd_rmsprop_ranges launch.  Same bits as the
+        # flat wfd_rmsprop pass; the weight-gradient views Dp.g / Gp.g of the matrices then stay unwritten.  Data parallel
+        # must all-reduce the gradients first and keeps the flat pass; so do K-split weight gradients (large batches).
+        self.fuse_opt = fuse_opt if fuse_opt in ("d", "g") else bool(fuse_opt)      # "d" / "g": one network only
         self.L = lib()
         self.dev = torch.device(device)
         S, C, Z, B = seq_len, class_dim, latent_dim, batch
@@ -307,6 +328,10 @@ class TrainEngine:
         self.gf_state = share.gf_state if share is not None else torch.zeros(2, dtype=torch.int64, device=dev)
         # fast mode, data parallel: all ranks hold the same permutation; rank r takes rows [r*B, (r+1)*B) of each
         # run of B*world indices and the cursor advances by the rows all ranks consumed
+        fuse = bool(self.fuse_opt) and not self.dp and not overlap
+        # the weight gradients contract over 2 M (critic) / B (generator) rows: unsplit below 1024 (Plan.gemm)
+        self.fuse_d = fuse and self.fuse_opt != "g" and 2 * M < 1024
+        self.fuse_g = fuse and self.fuse_opt != "d" and B < 1024
         self.row_offset = self.rank * B if self.dp else 0
         self.cursor_step = B * self.world
         self._fill_row_constants()
@@ -485,7 +510,17 @@ class TrainEngine:
         # product over the stacked [penalty ; standard] rows) runs beside it on the side lane as soon as its
         # operands exist
         Dp = D.p
-        if self.pair:
+        if self.fuse_d:
+            # single GPU: each t-chain product first (it reads W_i), then W_i's gradient with RMSprop in its store
+            lr = self.lr
+            ld1 = D.ld["model.0.weight"]
+            p.gemm_mul(NT, b["XC"], self.ldx, Dp["model.0.weight"], ld1, M, 2048, S, b["D1"], 2048, DM_MUL, None, b["T1H1"][:M], 2048)
+            p.gemm_rms(TN, b["DL1"], 2048, b["XC"], self.ldx, 2048, S + C, 2 * M, Dp["model.0.weight"], ld1, D.s["model.0.weight"], lr)
+            p.gemm_mul(NT, b["T1H1"][:M], 2048, Dp["model.3.weight"], 2048, M, 1024, 2048, b["D2"], 1024, DM_MUL, None, b["T2H2"][:M], 1024)
+            p.gemm_rms(TN, b["DL2"], 1024, b["T1H1"], 2048, 1024, 2048, 2 * M, Dp["model.3.weight"], 2048, D.s["model.3.weight"], lr)
+            p.gemm_mul(NT, b["T2H2"][:M], 1024, Dp["model.6.weight"], 1024, M, 512, 1024, b["D3"], 512, DM_MUL, None, b["T3"], 512)
+            p.gemm_rms(TN, b["DL3"], 512, b["T2H2"], 1024, 512, 1024, 2 * M, Dp["model.6.weight"], 1024, D.s["model.6.weight"], lr)
+        elif self.pair:
             # each layer's weight gradient (one TN product over the stacked [penalty ; standard] rows) shares a launch
             # with the t-chain product that follows it: neither reads what the other writes
             p.gemm_pair_mul((b["DL1"], 2048, b["XC"], self.ldx, 2048, S + C, 2 * M, D.g["model.0.weight"], D.ld["model.0.weight"]),
@@ -513,9 +548,22 @@ class TrainEngine:
             (b["V"], 1, b["RSELF"], None, 0, None, M, 1, b["dstats"][4:5])])
         p.join()
         self._grad_sync_hook(p, "D")
-        p.add(self.L.rmsprop, ptr(D.flat), ptr(D.grad), ptr(D.sq), D.numel, self.lr, 0.99, 1e-8, self.gscale,
-              st if fast else 0, self._rng_inc() if fast else 0, (self.cursor_step if own_cursor else 0) if fast else 0)
+        self._optimizer(p, D, self.fuse_d, st if fast else 0, self._rng_inc() if fast else 0,
+                        (self.cursor_step if own_cursor else 0) if fast else 0)
         return p
+
+    def _optimizer(self, p: Plan, fp: FlatParams, fused: bool, state: int, inc0: int, inc1: int):
+        """optimizer.step() (:230, :275): the flat RMSprop pass, or -- the matrices having been updated in their gradients'
+        stores -- the vectors only.  Either also advances the device-resident Philox counter / batch cursor."""
+        if not fused:
+            p.add(self.L.rmsprop, ptr(fp.flat), ptr(fp.grad), ptr(fp.sq), fp.numel, self.lr, 0.99, 1e-8, self.gscale,
+                  state, inc0, inc1)
+            return
+        flat = [v for r in fp.vector_ranges() for v in r]
+        arr = (ctypes.c_long * len(flat))(*flat)
+        p.keep.append(arr)
+        p.add(self.L.rmsprop_ranges, ptr(fp.flat), ptr(fp.grad), ptr(fp.sq), arr, len(flat) // 2, self.lr, 0.99, 1e-8,
+              state, inc0, inc1)
 
     def _d_backward_two_lane(self, p: Plan):
         """The same backward with every product its own launch: weight gradients on the side lane (overlap=True runs it
@@ -663,6 +711,23 @@ class TrainEngine:
         Gp = G.p
         # (weight gradient of layer k) and (activation gradient into layer k - 1) both read dz_k only: one launch each pair
         pr = self.pair
+        if self.fuse_g:
+            # single GPU: the activation gradient into layer k - 1 first (it reads W_k), then W_k's gradient with RMSprop in
+            # its store
+            lr = self.lr
+            s = p.gemm(NN, b["GDZ4"], self.lds4, Gp["model.8.weight"], 2048, B, 2048, S)
+            p.gemm_rms(TN, b["GDZ4"], self.lds4, b["GH3"], 2048, S, 2048, B, Gp["model.8.weight"], 2048, G.s["model.8.weight"], lr)
+            self._bn_bwd(p, s, 3, "model.5", "model.6", 2048)
+            s = p.gemm(NN, b["GDZ3"], 2048, Gp["model.5.weight"], 1024, B, 1024, 2048)
+            p.gemm_rms(TN, b["GDZ3"], 2048, b["GH2"], 1024, 2048, 1024, B, Gp["model.5.weight"], 1024, G.s["model.5.weight"], lr)
+            self._bn_bwd(p, s, 2, "model.2", "model.3", 1024)
+            p.gemm_mul(NN, b["GDZ2"], 1024, Gp["model.2.weight"], 512, B, 512, 1024, b["GH1"], 512, DM_RELU, None, b["GDZ1"], 512)
+            p.gemm_rms(TN, b["GDZ2"], 1024, b["GH1"], 512, 1024, 512, B, Gp["model.2.weight"], 512, G.s["model.2.weight"], lr)
+            p.add(self.L.colsum, ptr(b["GDZ1"]), 512, B, 512, 0, ptr(G.g["model.0.bias"]), 0)
+            p.gemm_rms(TN, b["GDZ1"], 512, b["ZIN"], self.ldz, 512, Z + C, B, Gp["model.0.weight"], G.ld["model.0.weight"],
+                       G.s["model.0.weight"], lr)
+            self._optimizer(p, G, True, st if fast else 0, self._rng_inc() if fast else 0, 0)
+            return p
         s = p.gemm_pair((b["GDZ4"], self.lds4, b["GH3"], 2048, S, 2048, B, G.g["model.8.weight"], 2048),
                         (NN, b["GDZ4"], self.lds4, Gp["model.8.weight"], 2048, B, 2048, S), pair=pr)
         self._grad_bucket_hook(p, "G", 0)
@@ -679,8 +744,7 @@ class TrainEngine:
                ldp=G.ld["model.0.weight"])
         p.join()
         self._grad_sync_hook(p, "G")
-        p.add(self.L.rmsprop, ptr(G.flat), ptr(G.grad), ptr(G.sq), G.numel, self.lr, 0.99, 1e-8, self.gscale,
-              st if fast else 0, self._rng_inc() if fast else 0, 0)
+        self._optimizer(p, G, False, st if fast else 0, self._rng_inc() if fast else 0, 0)
         return p
 
     def _bn_bwd(self, p: Plan, s: Slabs, i: int, lin: str, bn: str, n: int):
@@ -967,7 +1031,7 @@ class PipelinedTrainer:
         self.e = [eng, TrainEngine(eng.S, eng.C, eng.Z, eng.B, eng.scaler_min, eng.scaler_max, {}, {}, {}, lr=eng.lr,
                                    alpha=eng.alpha, n_critic=eng.n_critic, penalty=eng.penalty, lambda_gp=eng.lambda_gp,
                                    device=eng.dev, seed=eng.seed + 0x51ED, process_group=eng.pg, world_size=eng.world,
-                                   share=eng, rank=eng.rank, operands=eng.operands, wk=eng.wk)]
+                                   share=eng, rank=eng.rank, operands=eng.operands, wk=eng.wk, fuse_opt=eng.fuse_opt, pair=eng.pair)]
         other = self.e[1]
         for name in ("data_X", "data_y", "N", "perm", "perm_gen", "iters_per_epoch"):
             setattr(other, name, getattr(eng, name))
@@ -1096,7 +1160,8 @@ class GroupedTrainer:
         self.e = [TrainEngine(eng.S, eng.C, eng.Z, eng.B, eng.scaler_min, eng.scaler_max, {}, {}, {}, lr=eng.lr,
                               alpha=eng.alpha, n_critic=n, penalty=eng.penalty, lambda_gp=eng.lambda_gp, device=dev,
                               seed=eng.seed + 0x9E37 * (k + 1), process_group=eng.pg, world_size=eng.world, share=eng,
-                              rank=eng.rank, stacked=self.stacked, slot=k, operands=eng.operands, wk=eng.wk) for k in range(n)]
+                              rank=eng.rank, stacked=self.stacked, slot=k, operands=eng.operands, wk=eng.wk, fuse_opt=eng.fuse_opt, pair=eng.pair)
+                  for k in range(n)]
         self.base = eng
         for e in self.e:
             for name in ("data_X", "data_y", "N", "perm", "perm_gen", "iters_per_epoch"):

@@ -190,7 +190,8 @@ def main(argv=None):
         t = torch.tensor([seed], dtype=torch.int64, device=device)
         parallel.broadcast_state_([t])
         seed = int(t.item())
-    dp = dict(world_size=world, rank=rank, sync_bn=exact, operands=args.operands)
+    # single GPU: RMSprop runs inside the weight-gradient stores (engine.TrainEngine fuse_opt); data parallel keeps the flat pass
+    dp = dict(world_size=world, rank=rank, sync_bn=exact, operands=args.operands, fuse_opt=(world == 1))
     rng_seed = seed + 1000003 * rank
     eng = TrainEngine(seq_len, class_dim, args.latent_dim, B, scaler.data_min_[0], scaler.data_max_[0],
                       generator.state_dict(), discriminator.state_dict(), f_model.state_dict(), lr=args.lr,

@@ -216,6 +216,12 @@ class Plan:
         self.add(self.L.gemm_f32, layout, ptr(A), lda, ptr(B), ldb, ptr(self.ws), ldp, ss, M, N, K, ns)
         return Slabs(ptr(self.ws), ns, ss, ldp, M, N)
 
+    def gemm_rms(self, layout: int, A, lda: int, B, ldb: int, M: int, N: int, K: int, P, ldp: int, SQ, lr: float,
+                 alpha: float = 0.99, eps: float = 1e-8):
+        """A weight gradient consumed in its own store: RMSprop on the parameter matrix ``P`` / square average ``SQ``
+        (wfd_gemm_f32_rmsprop); the gradient is never written.  Unsplit contraction only."""
+        self.add(self.L.gemm_f32_rmsprop, layout, ptr(A), lda, ptr(B), ldb, M, N, K, ptr(P), ldp, ptr(SQ), lr, alpha, eps)
+
     def gemm_pair(self, tn, other, pair: bool = True) -> Slabs:
         """A weight gradient and the next product of the backward chain, which do not depend on each other, as ONE launch
         (wfd_gemm_f32_pair): tn = (A, lda, B, ldb, M, N, K, out, ldp) is the TN product written straight to ``out``;
