@@ -67,6 +67,7 @@ def build_engine(args, rank, world, device):
     eng = TrainEngine(S, C, Z, B, float(dmin[0]), float(dmax[0]), G.state_dict(), D.state_dict(), F.state_dict(),
                       lr=2e-4, alpha=0.02, n_critic=3, penalty=args.penalty, device=device, seed=1234 + rank,
                       process_group=pg, world_size=world, overlap=bool(args.overlap), rank=rank, sync_bn=strong,
+                      force_sync=bool(getattr(args, "force_dp", False)),
                       operands=args.operands, wk=bool(args.wk), fuse_opt={"0": False, "1": True}.get(args.fuse_opt, args.fuse_opt))
     eng.attach_dataset(Xs, y, shuffle_seed=0 if strong else rank)
     return eng, (dmin.double().cpu().numpy(), dmax.double().cpu().numpy())
@@ -224,6 +225,9 @@ def main():
     ap.add_argument("--fuse-opt", dest="fuse_opt", default="1", choices=["0", "1", "d", "g"],
                     help="1 (single GPU): RMSprop applied inside each weight gradient's store (wfd_gemm_f32_rmsprop), the "
                          "gradient never written; 0: gradient buffers + one flat optimizer pass (what data parallel runs)")
+    ap.add_argument("--force-dp", action="store_true",
+                    help="one GPU: run the data-parallel code path (bucketed gradient all-reduce over a 1-rank RCCL group, "
+                         "flat optimizer pass) to price its launch structure; WFD_DP_GRAPH=0 keeps the collectives out of the graphs")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-sampling", action="store_true")
     ap.add_argument("--no-modes", action="store_true", help="skip the bf16x3 / bf16 operand-mode runs of the same step")
@@ -236,6 +240,10 @@ def main():
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     device = torch.device(f"cuda:{local}")
     torch.cuda.set_device(device)
+    if args.force_dp and world == 1 and not torch.distributed.is_initialized():
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29571")
+        torch.distributed.init_process_group("nccl", rank=0, world_size=1)
 
     eng, (dmin, dmax) = build_engine(args, rank, world, device)
     strong = args.dp == "strong" and world > 1
@@ -398,6 +406,8 @@ def main():
                        "parallelism": f"dp{world}", "graphs": not args.no_graph, "pipelined": pipelined,
                        "grouped_generator_forwards": grouped, "length_index_saturated": saturated,
                        "operands": args.operands, "wk_fused_products": bool(args.wk),
+                       "dp_code_path_forced": bool(args.force_dp),
+                       "collectives_in_graph": parallel.graph_capturable(),
                        "optimizer_in_gradient_store": {"critic": bool(eng.fuse_d), "generator": bool(eng.fuse_g)}},
             "roofline": {"bound": "mfma", "achieved": roof["tflops"], "peak": peak, "unit": "TFLOP/s",
                          "frac": roof["tflops"] / peak, "traffic": traffic if args.operands == "f32" else None,
@@ -413,7 +423,7 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args, args.cpu_seconds)
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if torch.distributed.is_initialized():
         torch.distributed.destroy_process_group()
 
 

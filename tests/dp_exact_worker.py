@@ -173,3 +173,19 @@ def _run_weak(rank, world, name):
     dist.barrier()
     dist.destroy_process_group()
     return bad
+
+
+def generate_worker(rank, world, port, mdir, outp, n, q):
+    """`python -m wfd_gan_amd.generate` under torchrun: every rank samples its own contiguous shard of the label list with
+    its own seed and writes <out>.rank<r>.npz; no collective.  Ranks share cuda:0 (LOCAL_RANK 0), gloo."""
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK="0", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
+                      WFD_DIST_BACKEND="gloo")
+    msgs = []
+    try:
+        from wfd_gan_amd import generate
+        generate.main(["-m", mdir, "--n", str(n), "--chunk", "64", "--seed", "3", "--out", outp])
+        if torch.distributed.is_initialized():
+            torch.distributed.destroy_process_group()
+    except Exception as e:          # noqa: BLE001
+        msgs.append(f"rank {rank}: {type(e).__name__}: {e}")
+    q.put((rank, msgs))

@@ -8,7 +8,7 @@ import pytest
 import torch
 import torch.multiprocessing as mp
 
-from tests.dp_exact_worker import trainer_worker, weak_worker, worker
+from tests.dp_exact_worker import generate_worker, trainer_worker, weak_worker, worker
 
 pytestmark = pytest.mark.gpu
 
@@ -163,3 +163,46 @@ def test_bench_two_ranks_share_one_gpu(mode):
     steps = res["config"]["optimizer_steps_per_s"]
     assert abs(res["value"] - steps * (2 if mode == "weak" else 1)) < 1e-6 * res["value"]
     assert not [ln for ln in outs[1][0].splitlines() if ln.startswith("{")]          # only rank 0 prints
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_generate_cli_shards_the_label_list(world, tmp_path):
+    """generate.py under torchrun (src/generate.py's sample() in bulk, SURVEY.md 8e: embarrassingly parallel, no collective):
+    the ranks' files together hold labels arange(n) % C in order, shard sizes differ by at most one, and every rank's traces
+    are bit-identical to a single-process sampler with that rank's seed on that rank's labels."""
+    import numpy as np
+    from oracle import wfdgan_oracle as O
+    from wfd_gan_amd import generate, parallel
+    S, C, Z, n = 41, 5, 24, 301
+    mdir = tmp_path / "model"
+    mdir.mkdir()
+    torch.manual_seed(5)
+    torch.save(O.make_generator_state(S, C, Z), str(mdir / f"generator_seqlen{S}_cls{C}_latentdim{Z}.ckpt"))
+    dmin, dmax = np.zeros(S), np.concatenate([[40.0], np.tile([13.0, 122.0], S // 2)])[:S]
+    np.savez(str(mdir / "scaler.npz"), data_min=dmin, data_max=dmax)
+    outp = str(tmp_path / "t.npz")
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=generate_worker, args=(r, world, port, str(mdir), outp, n, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    out = [q.get(timeout=280) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+    bad = [m for _, msgs in out for m in msgs]
+    assert not bad, "\n".join(bad)
+    assert all(p.exitcode == 0 for p in procs)
+    labels, sizes = [], []
+    for r in range(world):
+        f = np.load(outp.replace(".npz", f".rank{r}.npz"))
+        a, b = parallel.shard_rows(n, r, world)
+        assert f["traces"].shape == (b - a, S) and f["lens"].shape == (b - a,)
+        labels.append(f["labels"])
+        sizes.append(b - a)
+        ts = generate.TraceSampler(str(mdir), device="cuda:0", chunk=64, seed=3 + r)
+        want, wlens = ts.sample_many(torch.arange(a, b) % C)
+        assert np.array_equal(f["traces"], want.cpu().numpy()) and np.array_equal(f["lens"], wlens.cpu().numpy())
+        assert (f["lens"] >= 1).all() and (f["traces"][np.arange(S)[None, :] < f["lens"][:, None]] > 0).all()
+    assert np.array_equal(np.concatenate(labels), np.arange(n) % C)
+    assert max(sizes) - min(sizes) <= 1 and sum(sizes) == n

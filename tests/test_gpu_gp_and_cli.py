@@ -127,11 +127,15 @@ def test_fast_mode_graph_equals_eager():
     assert torch.isfinite(e1.Dp.flat).all() and torch.isfinite(e1.Gp.flat).all()
 
 
-def test_data_parallel_staging_world1_nccl():
-    """The data-parallel code path (split BN kernels, graph stages around the bucketed asynchronous all-reduce over
-    RCCL) with a 1-rank NCCL group must reproduce the single-rank engine bit for bit."""
+@pytest.mark.parametrize("captured", [True, False])
+def test_data_parallel_world1_nccl(captured, monkeypatch):
+    """The data-parallel code path (bias gradients ahead of the weight gradients, bucketed asynchronous all-reduce over RCCL,
+    flat optimizer pass) with a 1-rank NCCL group must reproduce the single-rank engine bit for bit -- with the collectives
+    captured INSIDE the step graphs (one graph replay per D-step / G-step / group: the default on the "nccl" backend) and
+    with them issued eagerly between separately captured stages (WFD_DP_GRAPH=0)."""
     import torch.distributed as dist
-    from wfd_gan_amd.engine import TrainEngine
+    from wfd_gan_amd.engine import GroupedTrainer, TrainEngine
+    monkeypatch.setenv("WFD_DP_GRAPH", "1" if captured else "0")
     os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
     os.environ.setdefault("MASTER_PORT", "29533")
     if not dist.is_initialized():
@@ -139,18 +143,36 @@ def test_data_parallel_staging_world1_nccl():
     try:
         S, C, Z, B = 41, 5, 16, 8
         st, e1, Xs, y = _setup(S, C, Z, B, "div")
-        e2 = TrainEngine(S, C, Z, B, e1.scaler_min, e1.scaler_max, e1.generator_state(), e1.discriminator_state(),
-                         {k: v for k, v in st.DF.items()}, device=DEV, world_size=1, force_sync=True)
+        mk = lambda: TrainEngine(S, C, Z, B, e1.scaler_min, e1.scaler_max, e1.generator_state(), e1.discriminator_state(),
+                                 {k: v for k, v in st.DF.items()}, device=DEV, world_size=1, force_sync=True)
+        e2 = mk()
         for e in (e1, e2):
             e.attach_dataset(torch.from_numpy(Xs), torch.from_numpy(y), shuffle_seed=5)
             e.capture_graphs()
-        assert len(e2.graph_d) == 7 and len(e1.graph_d) == 1      # stage, start, stage, start, stage, start+finish, stage
+        # eager collectives: stage, start, stage, start, stage, start+finish, stage
+        assert len(e2.graph_d) == (1 if captured else 7) and len(e1.graph_d) == 1
+        assert (e2.graph_group is not None) == captured
         for i in range(7):
             e1.iteration(i)
             e2.iteration(i)
         torch.cuda.synchronize()
         assert torch.equal(e1.Dp.flat, e2.Dp.flat) and torch.equal(e1.Gp.flat, e2.Gp.flat)
         assert e1.d_stats() == e2.d_stats()
+        # the grouped driver (what bench.py runs under torchrun): one graph per group of n_critic iterations when captured
+        e3, e4 = mk(), TrainEngine(S, C, Z, B, e1.scaler_min, e1.scaler_max, e1.generator_state(), e1.discriminator_state(),
+                                   {k: v for k, v in st.DF.items()}, device=DEV)
+        outs = []
+        for e in (e3, e4):
+            e.attach_dataset(torch.from_numpy(Xs), torch.from_numpy(y), shuffle_seed=5)
+            grp = GroupedTrainer(e, graphs=True)
+            if e is e3:
+                assert len(grp.stages) == (1 if captured else 1 + 3 * 6 + 6)
+            for _ in range(3):
+                grp.run_group()
+            torch.cuda.synchronize()
+            outs.append((e.Dp.flat.clone(), e.Gp.flat.clone(), e.buf["dacc"].clone()))
+        for a, b in zip(*outs):
+            assert torch.equal(a, b)
     finally:
         dist.destroy_process_group()
 

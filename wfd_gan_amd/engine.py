@@ -232,6 +232,7 @@ class TrainEngine:
         # gradient buffers are all-reduced (sum) and RMSprop scales them by 1/world_size.
         self.pg, self.world = process_group, int(world_size)
         self._gsync = None
+        self.force_sync = bool(force_sync)
         self.dp = self.world > 1 or force_sync      # force_sync: run the staged data-parallel path at world 1 (tests)
         self.gscale = 1.0 if self.exact else 1.0 / self.world     # factor RMSprop applies to the summed gradients
         self._comm = None
@@ -415,7 +416,7 @@ class TrainEngine:
         if not self.exact:
             return
         mean, m2, B = self.buf[f"mean{layer}"], self.buf[f"m2{layer}"], self.B
-        p.host(lambda: self.comm.combine_bn_stats_(mean, m2, B))
+        p.host(lambda: self.comm.combine_bn_stats_(mean, m2, B), self.comm.capturable)
 
     def _critic_forward(self, p: Plan, X, M: int, mk, H1, H2, H3, D1, D2, D3, V, DL3, DL3s, rowscale):
         """Discriminator.forward (src/model.py:69-72) on M rows of X, keeping d_i; ends with the head + delta_3."""
@@ -619,9 +620,9 @@ class TrainEngine:
         bucket = fp.grad[lo:hi]
         gs = self._gsync
         if stage < 2:
-            p.host(lambda: gs.start(bucket))
+            p.host(lambda: gs.start(bucket), gs.capturable)
         else:
-            p.host(lambda: (gs.start(bucket), gs.finish()))
+            p.host(lambda: (gs.start(bucket), gs.finish()), gs.capturable)
 
     def grad_buckets(self, which: str):
         """[(begin, end)] x 3 element ranges of the flat gradient buffer, in the order the backward completes them."""
@@ -676,7 +677,7 @@ class TrainEngine:
         if not self.exact:
             return
         ghead = self.buf["ghead"]
-        p.host(lambda: self.comm.all_reduce_sum_(ghead))
+        p.host(lambda: self.comm.all_reduce_sum_(ghead), self.comm.capturable)
 
     def _build_g_plan(self, fast: bool = False, draw_masks: bool = True) -> Plan:
         B, S, C, Z, b, G = self.B, self.S, self.C, self.Z, self.buf, self.Gp
@@ -764,10 +765,10 @@ class TrainEngine:
         # is summed over ranks.
         sums, dgam, dbet, w = b[f"bns{i}"], G.g[f"{bn}.weight"], G.g[f"{bn}.bias"], float(self.world)
         p.add(self.L.bn_bwd, *args, 1)
-        p.host(lambda: self.comm.all_reduce_sum_(sums))
+        p.host(lambda: self.comm.all_reduce_sum_(sums), self.comm.capturable)
         p.add(self.L.bn_bwd, *args, 2)
         if self.world > 1:
-            p.host(lambda: (dgam.div_(w), dbet.div_(w)))
+            p.host(lambda: (dgam.div_(w), dbet.div_(w)), self.comm.capturable)
 
     # ------------------------------------------------------------------------------------------------------
     # inputs
@@ -938,7 +939,8 @@ class TrainEngine:
         self.graph_group = None
         if len(self.graph_d) == 1 and len(self.graph_g) == 1:
             g = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g):
+            kw = dict(capture_error_mode="thread_local") if (self.fast_d.has_collectives or self.fast_g.has_collectives) else {}
+            with torch.cuda.graph(g, **kw):
                 self.fast_d.run()
                 self.fast_g.run()
                 for _ in range(self.n_critic - 1):
@@ -954,7 +956,10 @@ class TrainEngine:
         for st in plan.stages():
             if isinstance(st, Plan):
                 g = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(g):
+                # collectives captured with the launches (RCCL): the backend's watchdog thread makes HIP calls of its own
+                # during the capture, which only the thread-local capture mode tolerates
+                kw = dict(capture_error_mode="thread_local") if st.has_collectives else {}
+                with torch.cuda.graph(g, **kw):
                     st.run()
                 g.keep = plan.keep          # the captured launches point into the plan's descriptor tables
                 out.append(g.replay)
@@ -1031,7 +1036,7 @@ class PipelinedTrainer:
         self.e = [eng, TrainEngine(eng.S, eng.C, eng.Z, eng.B, eng.scaler_min, eng.scaler_max, {}, {}, {}, lr=eng.lr,
                                    alpha=eng.alpha, n_critic=eng.n_critic, penalty=eng.penalty, lambda_gp=eng.lambda_gp,
                                    device=eng.dev, seed=eng.seed + 0x51ED, process_group=eng.pg, world_size=eng.world,
-                                   share=eng, rank=eng.rank, operands=eng.operands, wk=eng.wk, fuse_opt=eng.fuse_opt, pair=eng.pair)]
+                                   share=eng, rank=eng.rank, operands=eng.operands, wk=eng.wk, fuse_opt=eng.fuse_opt, pair=eng.pair, force_sync=eng.force_sync)]
         other = self.e[1]
         for name in ("data_X", "data_y", "N", "perm", "perm_gen", "iters_per_epoch"):
             setattr(other, name, getattr(eng, name))
@@ -1160,8 +1165,8 @@ class GroupedTrainer:
         self.e = [TrainEngine(eng.S, eng.C, eng.Z, eng.B, eng.scaler_min, eng.scaler_max, {}, {}, {}, lr=eng.lr,
                               alpha=eng.alpha, n_critic=n, penalty=eng.penalty, lambda_gp=eng.lambda_gp, device=dev,
                               seed=eng.seed + 0x9E37 * (k + 1), process_group=eng.pg, world_size=eng.world, share=eng,
-                              rank=eng.rank, stacked=self.stacked, slot=k, operands=eng.operands, wk=eng.wk, fuse_opt=eng.fuse_opt, pair=eng.pair)
-                  for k in range(n)]
+                              rank=eng.rank, stacked=self.stacked, slot=k, operands=eng.operands, wk=eng.wk, fuse_opt=eng.fuse_opt, pair=eng.pair,
+                              force_sync=eng.force_sync) for k in range(n)]
         self.base = eng
         for e in self.e:
             for name in ("data_X", "data_y", "N", "perm", "perm_gen", "iters_per_epoch"):

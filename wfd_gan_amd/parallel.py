@@ -26,6 +26,18 @@ def init_from_env(backend: Optional[str] = None) -> Tuple[int, int, int]:
     return rank, world, local
 
 
+def graph_capturable(group=None) -> bool:
+    """True when this group's collectives may be issued inside a HIP-graph capture: the "nccl" (RCCL) backend enqueues
+    them on its own stream ordered by events against the capturing stream, so start / wait become graph edges and a whole
+    data-parallel step replays as ONE graph.  gloo (host staging) cannot.  WFD_DP_GRAPH=0 keeps the collectives out of the
+    graphs (eager, between separately captured stages)."""
+    if not (dist.is_available() and dist.is_initialized()):
+        return True                  # no process group: the "collectives" are identities
+    if os.environ.get("WFD_DP_GRAPH", "1") == "0":
+        return False
+    return dist.get_backend(group) == "nccl"
+
+
 def allreduce_sum_(flat: torch.Tensor, group=None) -> torch.Tensor:
     """In-place sum of a flat gradient buffer over all ranks (the optimizer applies the 1/world factor)."""
     dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=group)
@@ -44,6 +56,7 @@ class Comm:
         self.world = dist.get_world_size(group) if self.active else 1
         self.rank = dist.get_rank(group) if self.active else 0
         self.staged = self.active and dist.get_backend(group) == "gloo"
+        self.capturable = graph_capturable(group)
 
     def all_reduce_sum_(self, t: torch.Tensor) -> torch.Tensor:
         if not self.active:
@@ -94,6 +107,8 @@ class GradSync:
         self.pending = []
         self.active = dist.is_available() and dist.is_initialized()
         self.staged = self.active and dist.get_backend(group) == "gloo"
+        # under capture start() / finish() become a fork onto RCCL's stream and the join before the optimizer kernel
+        self.capturable = graph_capturable(group)
 
     def start(self, bucket: torch.Tensor):
         if not self.active:                         # world 1 without a process group: the sum is the bucket itself

@@ -84,9 +84,12 @@ class Plan:
         self.calls += other.calls
         self.keep += other.keep
 
-    def host(self, thunk):
-        """A host-side action between launches (a collective): splits the plan into separately captured stages."""
-        self.calls.append((HOST, (thunk,), 0))
+    def host(self, thunk, capturable: bool = False):
+        """A host-side action between launches (a collective).  ``capturable``: the action only enqueues device work on
+        (or ordered after) the current stream and may therefore run INSIDE a HIP-graph capture -- a torch.distributed
+        collective on the "nccl" (RCCL) backend -- so the whole step stays one graph; any other action splits the plan into
+        separately captured stages with the action run eagerly in between."""
+        self.calls.append((HOST, (thunk, bool(capturable)), 0))
 
     def fork(self):
         """Following side-lane launches may start once everything issued on the main lane so far is done."""
@@ -150,7 +153,7 @@ class Plan:
         out, cur = [], mk()
         cur.keep = self.keep
         for fn, a, lane in self.calls:
-            if fn is HOST:
+            if fn is HOST and not a[1]:
                 if len(cur):
                     out.append(cur)
                 out.append(a[0])
@@ -164,6 +167,12 @@ class Plan:
 
     def __len__(self):
         return len(self.calls)
+
+    @property
+    def has_collectives(self) -> bool:
+        """Capturable host actions inside: capture with capture_error_mode="thread_local" (the collective backend's
+        watchdog thread issues HIP calls of its own while this thread captures)."""
+        return any(fn is HOST for fn, _, _ in self.calls)
 
     # -- contractions -------------------------------------------------------------------------------------
     def wk_cfg(self, layout: int, A, lda: int, B, ldb: int, M: int, N: int, K: int) -> int:
