@@ -169,9 +169,14 @@ def test_sample_post_modes_bit_exact(mode):
 
 @pytest.mark.parametrize("name", ["tiny", "cfg2"])
 def test_bulk_sampler_end_to_end(name):
-    """(seed, class) -> integer burst vector through the HIP generator.  The fp32 GEMMs sum in a different order
-    than the CPU's, so a value whose pre-round magnitude sits within 1e-3 of a half-integer (or a length within
-    1e-3 of an integer) may legitimately round the other way; everything else must be bit-exact."""
+    """(seed, class) -> integer burst vector through the HIP generator, against what the reference's Generator + sample()
+    (src/generate.py:48-64) produced for the same z (fixture).  The epilogue is bit-exact on identical floats
+    (test_sample_post_bit_exact); end to end the only freedom is the fp32 summation order of the four contractions.
+    Stated bound: the pre-round value (inverse-scaled sigmoid output) lies within 2e-6 of the column's range of the
+    fixture's (measured on the MI355X, tools/sampler_probe.py: 4.8e-7 of the range, i.e. 1.2e-4 on the burst count of
+    range 1400 and <= 2e-5 on the bursts -- one fp32 ulp), so an integer may differ from the fixture's only by 1 and only
+    where the fixture's pre-round value sits within that window of a half-integer (a length only where it sits that close
+    to an integer); at least 99 % of the rows must be bit-exact (measured: 150 of 150, 0 of 73 951 elements differ)."""
     from wfd_gan_amd.sampler import BulkSampler, minmax_params
     fx, meta = _load_sampler_fixture(name)
     S, C, Z = meta["seq_len"], meta["class_dim"], meta["latent_dim"]
@@ -185,25 +190,30 @@ def test_bulk_sampler_end_to_end(name):
         elif k.endswith("running_var"):
             gsd[k] = torch.rand(gsd[k].shape, generator=g) * 0.2 + 0.05
     n = fx["z"].shape[0]
-    bs = BulkSampler(gsd, S, C, Z, fx["data_min"], fx["data_max"], chunk=64, device=DEV)
+    bs = BulkSampler(gsd, S, C, Z, fx["data_min"], fx["data_max"], chunk=n, device=DEV)      # one chunk: bs.y keeps every row
     out, lens = bs.generate(torch.from_numpy(fx["c"]), torch.from_numpy(fx["z"]))
     out, lens = out.cpu().numpy().astype(np.int64), lens.cpu().numpy()
     scale, min_ = minmax_params(fx["data_min"], fx["data_max"])
-    exact_rows, checked = 0, 0
+    rng = np.maximum(np.asarray(fx["data_max"], dtype=np.float64) - np.asarray(fx["data_min"], dtype=np.float64), 1.0)
+    window = 2e-6 * rng
+    y = bs.y[:n, :S].cpu().numpy()
+    pre_gpu = O.inverse_transform_f32(y, scale, min_).astype(np.float64)
+    pre_ref = O.inverse_transform_f32(fx["y"], scale, min_).astype(np.float64)
+    both = (y != 0) & (fx["y"] != 0)
+    assert (np.abs(pre_gpu - pre_ref) * both <= window[None, :]).all(), "pre-round values outside the fp32 reordering bound"
+    exact_rows = 0
     for i in range(n):
-        pre = O.inverse_transform_f32(fx["y"][i].reshape(1, -1), scale, min_).flatten()
-        frac = np.abs(pre - np.floor(pre) - 0.5)
+        pre = pre_ref[i]
         if lens[i] != fx["out_len"][i]:
-            # only allowed when the learned length is within 1e-3 of an integer boundary
-            assert abs(pre[0] - np.round(pre[0])) < 1e-2, (i, pre[0])
+            assert abs(int(lens[i]) - int(fx["out_len"][i])) == 1 and abs(pre[0] - np.round(pre[0])) <= window[0], (i, pre[0])
             continue
         ln = lens[i]
         diff = out[i][:ln] != fx["out"][i][:ln]
+        frac = np.abs(pre - np.floor(pre) - 0.5)
         assert np.all(np.abs(out[i][:ln] - fx["out"][i][:ln]) <= 1)
-        assert np.all(frac[:ln][diff] < 1e-2), f"row {i}: mismatch away from a rounding boundary"
+        assert np.all(frac[:ln][diff] <= window[:ln][diff]), f"row {i}: mismatch away from a rounding boundary"
         exact_rows += int(not diff.any())
-        checked += 1
-    assert exact_rows >= 0.9 * checked
+    assert exact_rows >= 0.99 * n, f"{exact_rows} of {n} rows bit-exact"
 
 
 def test_clip_bursts_kernel():

@@ -940,27 +940,44 @@ class TrainEngine:
         if len(self.graph_d) == 1 and len(self.graph_g) == 1:
             g = torch.cuda.CUDAGraph()
             kw = dict(capture_error_mode="thread_local") if (self.fast_d.has_collectives or self.fast_g.has_collectives) else {}
-            with torch.cuda.graph(g, **kw):
-                self.fast_d.run()
-                self.fast_g.run()
-                for _ in range(self.n_critic - 1):
+            try:
+                with torch.cuda.graph(g, **kw):
                     self.fast_d.run()
-            self.graph_group = g
+                    self.fast_g.run()
+                    for _ in range(self.n_critic - 1):
+                        self.fast_d.run()
+                self.graph_group = g
+            except RuntimeError:
+                if not kw:
+                    raise
+                torch.cuda.synchronize()       # collectives refused this capture: single-step graphs only
         torch.cuda.synchronize()
         self._restore(snap)
 
     @staticmethod
-    def _capture_stages(plan: Plan):
-        """One HIP graph per run of launches; host actions (collectives) stay eager between the replays."""
+    def _capture_stages(plan: Plan, split_all: bool = False):
+        """One HIP graph per run of launches; host actions that cannot be captured stay eager between the replays.  If
+        capturing a run WITH its collectives fails (a collective backend that refuses stream capture), the plan is split
+        at every host action instead and the collectives run eagerly between the stages."""
         out = []
-        for st in plan.stages():
+        for st in plan.stages(split_all):
             if isinstance(st, Plan):
                 g = torch.cuda.CUDAGraph()
                 # collectives captured with the launches (RCCL): the backend's watchdog thread makes HIP calls of its own
                 # during the capture, which only the thread-local capture mode tolerates
-                kw = dict(capture_error_mode="thread_local") if st.has_collectives else {}
-                with torch.cuda.graph(g, **kw):
-                    st.run()
+                coll = st.has_collectives
+                kw = dict(capture_error_mode="thread_local") if coll else {}
+                try:
+                    with torch.cuda.graph(g, **kw):
+                        st.run()
+                except RuntimeError:
+                    if not coll:
+                        raise
+                    import warnings
+                    warnings.warn("capturing the data-parallel collectives inside the step graph failed; "
+                                  "falling back to eager collectives between graph stages")
+                    torch.cuda.synchronize()
+                    return TrainEngine._capture_stages(plan, split_all=True)
                 g.keep = plan.keep          # the captured launches point into the plan's descriptor tables
                 out.append(g.replay)
             else:

@@ -147,13 +147,14 @@ class Plan:
             else:
                 fn(*a, ss if lane else ms)
 
-    def stages(self):
-        """[Plan | thunk, ...]: maximal runs of launches separated by host actions."""
+    def stages(self, split_all: bool = False):
+        """[Plan | thunk, ...]: maximal runs of launches separated by host actions (capturable ones stay inside their run
+        unless ``split_all``)."""
         mk = lambda: Plan(self.ws_lane[0], self.ws_lane[1] if self.two else None, self.overlap, self.gemm_mode, self.wk)
         out, cur = [], mk()
         cur.keep = self.keep
         for fn, a, lane in self.calls:
-            if fn is HOST and not a[1]:
+            if fn is HOST and (split_all or not a[1]):
                 if len(cur):
                     out.append(cur)
                 out.append(a[0])
