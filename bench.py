@@ -271,17 +271,24 @@ def main():
     # The timed block is EXACTLY --steps iterations between barrier + synchronize on both sides, max over ranks.  It is
     # repeated --repeats times back to back (training simply continues) and the MEDIAN block time is reported, so that a
     # short block (the driver's --steps 20 is 7 ms) says the same as a long one; every block's time is in `block_ms`.
-    # A --steps that is no multiple of n_critic ends with 1-2 single iterations (their G-step falls where the reference's
-    # schedule puts it), which cost more per iteration than whole groups: that is the schedule, not noise.
+    # A --steps that is no multiple of n_critic ends every block with 1-2 single iterations whose G-step falls where the
+    # global iteration index puts it (i % n_critic == 0): blocks then differ by SCHEDULE (6 or 7 G-steps in 20 iterations),
+    # not by noise.  In that case the number of blocks is rounded up to a multiple of n_critic (the start index advances by
+    # --steps per block, so n_critic consecutive blocks see every phase once) and the MEAN block time is reported.
+    nc = eng.n_critic
+    ragged = args.steps % nc != 0
+    nblocks = max(1, args.repeats)
+    if ragged:
+        nblocks = (nblocks + nc - 1) // nc * nc
     dts, it0 = [], args.warmup
-    for _ in range(max(1, args.repeats)):
+    for _ in range(nblocks):
         barrier()
         t0 = time.perf_counter()
         run_steps(drv, it0, args.steps)
         barrier()
         dts.append(parallel.max_over_ranks(time.perf_counter() - t0, device))
         it0 += args.steps
-    dt = float(np.median(dts))
+    dt = float(np.mean(dts)) if ragged else float(np.median(dts))
     # On this synthetic recipe (burst counts up to L) the generator's length head saturates after ~2000 iterations and
     # the reference raises IndexError there (src/model.py:44; the CPU oracle does after 1.2 epochs, DESIGN.md section
     # 6).  The kernels clamp the index, so a long timing run stays valid; the condition is reported, not raised.
@@ -300,9 +307,11 @@ def main():
 
     # the launches of the plans that were timed above (one group of n_critic iterations either way)
     roof = gemm_roofline(eng, [(drv.group, 1)] if grouped else None)
-    traffic = None          # HBM bytes per GEMM launch from the committed PMC passes (tools/pmc_traffic.py)
+    traffic, traffic_commit = None, None      # HBM bytes per contraction launch from the committed PMC passes (tools/pmc_traffic.py)
     try:
-        traffic = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))["_gemm_all"]["hbm_bytes_per_launch"]
+        pm = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))
+        traffic = pm["_gemm_all"]["hbm_bytes_per_launch"]
+        traffic_commit = pm.get("_meta", {}).get("commit")
     except Exception:
         pass
     samp = None
@@ -394,7 +403,8 @@ def main():
             "metric": "WGAN train iterations/s (100-class, L=1400, fp32; one iteration = loop body on one 64-row batch: "
                       "D-step every iteration, G-step every 3rd; N GPUs weak-scaled = N such batches per optimizer step)",
             "value": its * 1.0, "unit": "iterations/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": ms_per_step, "timed_blocks": len(dts), "block_ms": [round(x * 1e3, 3) for x in dts],
+            "ms_per_step": ms_per_step, "timed_blocks": len(dts), "block_stat": "mean" if ragged else "median",
+            "block_ms": [round(x * 1e3, 3) for x in dts],
             "higher_is_better": True, "scaling": "strong" if (args.dp == "strong" and world > 1) else "weak",
             "vs_baseline": None,
             "dtype": dtype, "data": "synthetic",
@@ -411,8 +421,9 @@ def main():
                        "optimizer_in_gradient_store": {"critic": bool(eng.fuse_d), "generator": bool(eng.fuse_g)}},
             "roofline": {"bound": "mfma", "achieved": roof["tflops"], "peak": peak, "unit": "TFLOP/s",
                          "frac": roof["tflops"] / peak, "traffic": traffic if args.operands == "f32" else None,
-                         "traffic_note": "bytes/launch, rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command "
-                                         "(profiles/pmc_traffic.json; FETCH x2 per MI355X_MICROARCH HBM section)",
+                         "traffic_note": "bytes/launch, NOT measured in this run: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of "
+                                         "this command (--no-graph --steps 12) committed as profiles/pmc_traffic.json, taken at "
+                                         f"commit {traffic_commit}; FETCH x2 per MI355X_MICROARCH HBM section",
                          "kernel": core, "launches_timed": roof["launches"],
                          "avg_flops_per_launch": roof["avg_flops"], "avg_us_per_launch": roof["avg_us"]},
         }
