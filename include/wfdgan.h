@@ -154,6 +154,15 @@ int wfd_colsum(const float* X, int ldx, int M, int N, const float* rowscale, flo
  * columns each.  With N = 1 segments this also produces the step's loss scalars (:218,226-227) on device. */
 int wfd_colsum_multi(const long long* desc, int nseg, int total_blocks, void* stream);
 
+/* wfd_colsum_multi whose outputs are parameter gradients consumed on the spot: an output that lies inside the flat
+ * gradient buffer [gbase, gbase + numel) is still written, and its parameter -- same offset in pbase / sqbase -- takes
+ * its RMSprop step (torch defaults, as wfd_rmsprop) in the same launch: d_loss.backward() + optimizer_D.step() for the
+ * biases and the critic's head (src/mlp_df_wgan_train.py:229-230), whose gradients ARE column sums.  Outputs elsewhere
+ * (loss scalars) are plain.  Bookkeeping as wfd_rmsprop: state[0] += inc0, state[1] += inc1 (state may be NULL). */
+int wfd_colsum_multi_rmsprop(const long long* desc, int nseg, int total_blocks, const float* gbase, float* pbase,
+                             float* sqbase, long numel, float lr, float alpha, float eps, unsigned long long* state,
+                             unsigned long long inc0, unsigned long long inc1, void* stream);
+
 /* torch.optim.RMSprop.step with torch defaults (alpha .99, eps 1e-8), src/mlp_df_wgan_train.py:163-164,230,275,
  * over one flat parameter buffer; g is multiplied by gscale first (1/world_size after an all-reduce).  As the
  * last kernel of a step it can also do the step's bookkeeping: state[0] += inc0, state[1] += inc1 (state may be
@@ -190,6 +199,14 @@ int wfd_bn_apply_relu(const float* Z, int ldz, int M, int N, const float* mean, 
                       float* rvar, float momentum, int nupd, void* stream);
 int wfd_bn_running_update(const float* mean, const float* m2, float count, int N, float* rmean, float* rvar,
                           float momentum, int nupd, void* stream);
+
+/* The running-statistics updates of BOTH BatchNorm layers of the generator (src/model.py:30-31) for `groups` stacked
+ * training-mode forwards in one launch: per layer, batches g = 0..groups-1 (mean / m2 [groups][N]) are applied in
+ * order, the last one nupd_last times (the G-step's second generator(z, c) on the same batch,
+ * src/mlp_df_wgan_train.py:196,240).  Same operations, element for element, as wfd_bn_running_update batch by batch. */
+int wfd_bn_running_update_layers(const float* meanA, const float* m2A, int NA, float* rmeanA, float* rvarA,
+                                 const float* meanB, const float* m2B, int NB, float* rmeanB, float* rvarB, float count,
+                                 float momentum, int groups, int nupd_last, void* stream);
 
 /* Backward of ReLU + BatchNorm1d (training) (:273). phase bit 0: local column sums (sums[0..N) = sum dy,
  * sums[N..2N) = sum dy*xhat); bit 1: dz, dgamma, dbeta and the preceding Linear's bias gradient. */
@@ -242,6 +259,12 @@ int wfd_masked_ce(const float* logits, int ldl, int M, int C, const int* labels,
 
 /* out[4] = {g_loss, f_loss, g_loss + alpha f_loss, nsel}; acc[4] += {g_loss, f_loss, combined, 1} (:263-271) */
 int wfd_g_loss(const float* ce, int B, const float* head, float alpha, float* out, float* acc, void* stream);
+
+/* wfd_g_head + wfd_masked_ce + wfd_g_loss in ONE launch (one workgroup; B <= 256: the batches of the reference's
+ * configuration), src/mlp_df_wgan_train.py:247-271: head[2] = {-mean(fv), #{fv > 0}}, ce / dlogits as wfd_masked_ce,
+ * out[4] / acc[4] as wfd_g_loss.  Single rank only (the exact data-parallel mode all-reduces head in between). */
+int wfd_g_tail(const float* logits, int ldl, int B, int C, const int* labels, const float* fv, float invB, float alpha,
+               float* ce, float* dlogits, int lddl, float* head, float* out, float* acc, void* stream);
 
 /* input gradient of the first conv: dX[b][l] = sum_{co,t} W[co][t] dC[b][l-t+3][co] (:273) */
 int wfd_df_conv1_bwd(const float* dC, int Bn, int L, int Cout, const float* W, float* dX, int lddx, void* stream);

@@ -10,7 +10,8 @@ import re
 from typing import Callable, Dict, List, Tuple
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libwfdgan_hip.so")
+# WFD_LIB_PATH: another build of the same library (same-session A/B of kernel variants on one GPU box); no fallback either way
+LIB_PATH = os.environ.get("WFD_LIB_PATH") or os.path.join(_HERE, "libwfdgan_hip.so")
 HEADER_PATH = os.path.join(os.path.dirname(_HERE), "include", "wfdgan.h")
 
 _SCALARS = {

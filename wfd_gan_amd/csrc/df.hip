@@ -143,6 +143,53 @@ __global__ void g_loss_kernel(const float* __restrict__ ce, int B, const float* 
     (void)nsel_global_scale;
 }
 
+// The three launches above plus g_head (epilogues.hip) as ONE workgroup, for the batches of the B = 64 step (<= 256 rows):
+// head = [-sum fv / B, #{fv > 0}], masked cross-entropy per row (one wave per row, 16 waves), then the G-step scalars.
+// Per-row arithmetic is masked_ce_kernel's; only the order of the two batch sums differs (wave partials in wave order).
+__global__ __launch_bounds__(1024) void g_tail_kernel(const float* __restrict__ logits, int ldl, int B, int C,
+                                                      const int* __restrict__ labels, const float* __restrict__ fv,
+                                                      float invB, float alpha, float* __restrict__ ce,
+                                                      float* __restrict__ dlogits, int lddl, float* __restrict__ head,
+                                                      float* __restrict__ out, float* __restrict__ acc) {
+    __shared__ float red[16];
+    __shared__ float hd[2];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
+    float s = 0.f, c = 0.f;
+    for (int i = threadIdx.x; i < B; i += blockDim.x) { s += fv[i]; c += fv[i] > 0.f ? 1.f : 0.f; }
+    s = block_sum(s, red);
+    c = block_sum(c, red);
+    if (threadIdx.x == 0) { hd[0] = -s * invB; hd[1] = c; head[0] = hd[0]; head[1] = c; }
+    __syncthreads();
+    const float nsel = hd[1];
+    float cesum = 0.f;
+    for (int m = wave; m < B; m += nw) {
+        const float* row = logits + (long)m * ldl;
+        float mx = -INFINITY;
+        for (int k = lane; k < C; k += 64) mx = fmaxf(mx, row[k]);
+        mx = wave_max(mx);
+        float e = 0.f;
+        for (int k = lane; k < C; k += 64) e += expf(row[k] - mx);
+        e = wave_sum(e);
+        const float lse = mx + logf(e);
+        const int lab = labels[m];
+        const float sel = fv[m] > 0.f ? 1.f : 0.f;
+        const float w = nsel > 0.f ? alpha * sel / nsel : 0.f;
+        const float cem = sel * (lse - row[lab]);
+        if (lane == 0) { ce[m] = cem; cesum += cem; }
+        for (int k = lane; k < C; k += 64) {
+            const float p = expf(row[k] - lse);
+            dlogits[(long)m * lddl + k] = w * (p - (k == lab ? 1.f : 0.f));
+        }
+    }
+    cesum = block_sum(cesum, red);
+    if (threadIdx.x == 0) {
+        const float fl = nsel > 0.f ? cesum / nsel : 0.f;
+        const float gl = hd[0];
+        out[0] = gl; out[1] = fl; out[2] = gl + alpha * fl; out[3] = nsel;
+        if (acc) { acc[0] += gl; acc[1] += fl; acc[2] += gl + alpha * fl; acc[3] += 1.f; }
+    }
+}
+
 // dX[b][l] = sum_{co,t} W[co][t] * dC[b][l - t + 3][co]   (input gradient of the Cin = 1 conv)
 // block: one sample x 64 positions; LDS holds dC rows l0-4 .. l0+66.
 __global__ void conv1_bwd_kernel(const float* __restrict__ dC, int L, int Cout, const float* __restrict__ W,
@@ -220,6 +267,15 @@ int wfd_masked_ce(const float* logits, int ldl, int M, int C, const int* labels,
     if (!logits || !labels || !fv || !nsel || !ce || !dlogits) return WFD_ERR_ARG;
     hipLaunchKernelGGL(masked_ce_kernel, dim3(M), dim3(64), 0, (hipStream_t)stream, logits, ldl, C, labels, fv, nsel,
                        alpha, ce, dlogits, lddl);
+    WFD_CHECK_LAUNCH();
+    return WFD_OK;
+}
+
+int wfd_g_tail(const float* logits, int ldl, int B, int C, const int* labels, const float* fv, float invB, float alpha,
+               float* ce, float* dlogits, int lddl, float* head, float* out, float* acc, void* stream) {
+    if (!logits || !labels || !fv || !ce || !dlogits || !head || !out || B < 1 || B > 256 || C < 1) return WFD_ERR_ARG;
+    hipLaunchKernelGGL(g_tail_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, logits, ldl, B, C, labels, fv, invB,
+                       alpha, ce, dlogits, lddl, head, out, acc);
     WFD_CHECK_LAUNCH();
     return WFD_OK;
 }

@@ -316,8 +316,17 @@ __global__ void colsum_kernel(const float* __restrict__ X, int ldx, int M, int N
 // Several column sums in ONE launch (all bias / head gradients and the loss scalars of a step).  desc holds, per
 // segment, 11 words: [X, ldx, rowscale, X2, ldx2, rowscale2, M, N, out, first_block, acc]   (X2 = 0: single source)
 //   out[n] = sum_m X[m][n] * rs[m] + sum_m X2[m][n] * rs2[m];   acc[n] += out[n] when acc != 0 (epoch sums)
-__global__ void colsum_multi_kernel(const long long* __restrict__ desc, int nseg) {
+// OPT: an output that lies inside the flat gradient buffer [gbase, gbase + numel) is a parameter gradient: its parameter
+// (same offset in pbase / sqbase) takes its RMSprop step right here (the vectors of a network whose matrices are updated in
+// their gradients' stores), and block 0 does the step's bookkeeping (state[0] += inc0, state[1] += inc1).
+struct ColsumOpt { const float* gbase; float* pbase; float* sqbase; long numel; float lr, alpha, eps;
+                   unsigned long long* state; unsigned long long inc0, inc1; };
+template <bool OPT>
+__global__ void colsum_multi_kernel(const long long* __restrict__ desc, int nseg, ColsumOpt o) {
     __shared__ float red[RG][CT];
+    if constexpr (OPT) {
+        if (o.state && blockIdx.x == 0 && threadIdx.x == 0 && threadIdx.y == 0) { o.state[0] += o.inc0; o.state[1] += o.inc1; }
+    }
     int sgi = 0;
     for (int k = 1; k < nseg; ++k)
         if ((int)desc[k * 11 + 9] <= (int)blockIdx.x) sgi = k;
@@ -341,6 +350,15 @@ __global__ void colsum_multi_kernel(const long long* __restrict__ desc, int nseg
     if (n < N && threadIdx.y == 0) {
         out[n] = a;
         if (acc) acc[n] += a;
+        if constexpr (OPT) {
+            const long off = (out + n) - o.gbase;
+            if (off >= 0 && off < o.numel) {
+                float pv = o.pbase[off], sv = o.sqbase[off];
+                rmsprop_update(pv, sv, a, o.lr, o.alpha, o.eps);
+                o.sqbase[off] = sv;
+                o.pbase[off] = pv;
+            }
+        }
     }
 }
 
@@ -599,6 +617,27 @@ __global__ void bn_running_update_kernel(const float* __restrict__ mean, const f
     }
     rmean[n] = rm;
     rvar[n] = rv;
+}
+
+// Both BatchNorm layers of the generator in one launch, for a whole group of stacked forwards: blockIdx.y selects the
+// layer; its `groups` batches are applied in order, the last one `nupd_last` times (the G-step's second forward of the same
+// batch, src/mlp_df_wgan_train.py:240).  Element for element the operations of bn_running_update_kernel applied batch by batch.
+struct BnLayer { const float* mean; const float* m2; float* rmean; float* rvar; int N; };
+__global__ void bn_running_update_layers_kernel(BnLayer a, BnLayer b, float count, float momentum, int groups, int nupd_last) {
+    const BnLayer& l = blockIdx.y ? b : a;
+    const int n = blockIdx.x * blockDim.x + threadIdx.x;
+    if (n >= l.N) return;
+    float rm = l.rmean[n], rv = l.rvar[n];
+    for (int g = 0; g < groups; ++g) {
+        const float mu = l.mean[(long)g * l.N + n], uv = l.m2[(long)g * l.N + n] / (count - 1.f);
+        const int nu = g == groups - 1 ? nupd_last : 1;
+        for (int u = 0; u < nu; ++u) {
+            rm = (1.f - momentum) * rm + momentum * mu;
+            rv = (1.f - momentum) * rv + momentum * uv;
+        }
+    }
+    l.rmean[n] = rm;
+    l.rvar[n] = rv;
 }
 
 // BatchNorm backward through ReLU.  dy = sumP o [H > 0].
@@ -1025,7 +1064,18 @@ int wfd_colsum(const float* X, int ldx, int M, int N, const float* rowscale, flo
 
 int wfd_colsum_multi(const long long* desc, int nseg, int total_blocks, void* stream) {
     if (!desc || nseg <= 0 || total_blocks <= 0) return WFD_ERR_ARG;
-    hipLaunchKernelGGL(colsum_multi_kernel, dim3(total_blocks), dim3(CT, RG), 0, (hipStream_t)stream, desc, nseg);
+    hipLaunchKernelGGL(colsum_multi_kernel<false>, dim3(total_blocks), dim3(CT, RG), 0, (hipStream_t)stream, desc, nseg,
+                       ColsumOpt{});
+    WFD_CHECK_LAUNCH();
+    return WFD_OK;
+}
+
+int wfd_colsum_multi_rmsprop(const long long* desc, int nseg, int total_blocks, const float* gbase, float* pbase,
+                             float* sqbase, long numel, float lr, float alpha, float eps, unsigned long long* state,
+                             unsigned long long inc0, unsigned long long inc1, void* stream) {
+    if (!desc || nseg <= 0 || total_blocks <= 0 || !gbase || !pbase || !sqbase || numel <= 0) return WFD_ERR_ARG;
+    ColsumOpt o{gbase, pbase, sqbase, numel, lr, alpha, eps, state, inc0, inc1};
+    hipLaunchKernelGGL(colsum_multi_kernel<true>, dim3(total_blocks), dim3(CT, RG), 0, (hipStream_t)stream, desc, nseg, o);
     WFD_CHECK_LAUNCH();
     return WFD_OK;
 }
@@ -1122,6 +1172,19 @@ int wfd_bn_running_update(const float* mean, const float* m2, float count, int N
     if (!mean || !m2 || !rmean || !rvar) return WFD_ERR_ARG;
     hipLaunchKernelGGL(bn_running_update_kernel, dim3(cdiv(N, 256)), dim3(256), 0, (hipStream_t)stream, mean, m2, count,
                        N, rmean, rvar, momentum, nupd, 1);
+    WFD_CHECK_LAUNCH();
+    return WFD_OK;
+}
+
+int wfd_bn_running_update_layers(const float* meanA, const float* m2A, int NA, float* rmeanA, float* rvarA,
+                                 const float* meanB, const float* m2B, int NB, float* rmeanB, float* rvarB, float count,
+                                 float momentum, int groups, int nupd_last, void* stream) {
+    if (!meanA || !m2A || !rmeanA || !rvarA || !meanB || !m2B || !rmeanB || !rvarB || NA < 1 || NB < 1 || groups < 1 ||
+        nupd_last < 0 || count <= 1.f)
+        return WFD_ERR_ARG;
+    BnLayer a{meanA, m2A, rmeanA, rvarA, NA}, b{meanB, m2B, rmeanB, rvarB, NB};
+    hipLaunchKernelGGL(bn_running_update_layers_kernel, dim3(cdiv(NA > NB ? NA : NB, 256), 2), dim3(256), 0,
+                       (hipStream_t)stream, a, b, count, momentum, groups, nupd_last);
     WFD_CHECK_LAUNCH();
     return WFD_OK;
 }

@@ -366,8 +366,10 @@ int wfd_gemm_wk_pick(int layout, int M, int N, int K) {
     const int nchunk = cdiv(K, KC);
     if (layout == 3) {
         // conv rows are plentiful: one wave pair per 32 x 32 tile while K is short
-        if (t32 < 96) return 0;
-        return nchunk >= 16 ? 1 : 5;
+        if (t32 >= 96) return nchunk >= 16 ? 1 : 5;
+        // the short, wide convs at the bottom of the observer (few rows, K = 8 Cin >= 1024): 32 x 16 tiles with K over 8 waves
+        // instead of split-K slabs + a consumer launch
+        return (t16 >= 32 && nchunk >= 16) ? 4 : 0;
     }
     if (M > 256) return 0;
     if (t32 >= 192) return nchunk >= 32 ? 2 : 1;

@@ -329,6 +329,7 @@ class TrainEngine:
         self.gf_state = share.gf_state if share is not None else torch.zeros(2, dtype=torch.int64, device=dev)
         # fast mode, data parallel: all ranks hold the same permutation; rank r takes rows [r*B, (r+1)*B) of each
         # run of B*world indices and the cursor advances by the rows all ranks consumed
+        self.g_tail_fused = not self.exact and B <= 256
         fuse = bool(self.fuse_opt) and not self.dp and not overlap
         # the weight gradients contract over 2 M (critic) / B (generator) rows: unsplit below 1024 (Plan.gemm)
         self.fuse_d = fuse and self.fuse_opt != "g" and 2 * M < 1024
@@ -537,6 +538,9 @@ class TrainEngine:
                             b["D3"], 512, DM_MUL, b["T3"], 512)
         else:
             self._d_backward_two_lane(p)
+        st_arg = (st if fast else 0, self._rng_inc() if fast else 0, (self.cursor_step if own_cursor else 0) if fast else 0)
+        # single GPU with the matrices updated in their gradients' stores: every remaining critic parameter (biases, head) has
+        # its gradient produced by THIS launch, which then applies their RMSprop step too and ends the D-step
         self._colsum_multi(p, "d_small", bias_segs + [
             (b["T3"], 512, None, b["H3"], 512, b["DV"], M, 512, D.g["model.9.weight"]),
             (b["DV"], 1, None, None, 0, None, M, 1, D.g["model.9.bias"]),
@@ -546,11 +550,12 @@ class TrainEngine:
             (b["PEN"], 1, b["INVB"], None, 0, None, M, 1, b["dstats"][1:2]),
             (b["V"], 1, b["NDV"], None, 0, None, M, 1, b["dstats"][2:3], b["dacc"][1:2]),
             (b["V"], 1, b["RSELR"], None, 0, None, M, 1, b["dstats"][3:4]),
-            (b["V"], 1, b["RSELF"], None, 0, None, M, 1, b["dstats"][4:5])])
+            (b["V"], 1, b["RSELF"], None, 0, None, M, 1, b["dstats"][4:5])], opt=(D, st_arg) if self.fuse_d else None)
+        if self.fuse_d:
+            return p
         p.join()
         self._grad_sync_hook(p, "D")
-        self._optimizer(p, D, self.fuse_d, st if fast else 0, self._rng_inc() if fast else 0,
-                        (self.cursor_step if own_cursor else 0) if fast else 0)
+        self._optimizer(p, D, False, *st_arg)
         return p
 
     def _optimizer(self, p: Plan, fp: FlatParams, fused: bool, state: int, inc0: int, inc1: int):
@@ -590,8 +595,10 @@ class TrainEngine:
         s = p.gemm(NT, b["T2H2"][:M], 1024, Dp["model.6.weight"], 1024, M, 512, 1024)
         p.mul(s, b["D3"], 512, DM_MUL, None, None, b["T3"], None, 512)
 
-    def _colsum_multi(self, p: Plan, name: str, segs):
-        """segs: (X, ldx, rowscale, X2, ldx2, rowscale2, M, N, out) -> one launch of wfd_colsum_multi."""
+    def _colsum_multi(self, p: Plan, name: str, segs, opt=None):
+        """segs: (X, ldx, rowscale, X2, ldx2, rowscale2, M, N, out) -> one launch of wfd_colsum_multi.
+        opt = (FlatParams, (state, inc0, inc1)): outputs inside that network's gradient buffer also take their RMSprop
+        step in the launch (wfd_colsum_multi_rmsprop), which then does the step's bookkeeping."""
         rows, blk = [], 0
         for sg in segs:
             X, ldx, rs, X2, ldx2, rs2, M, N, out = sg[:9]
@@ -600,7 +607,12 @@ class TrainEngine:
             blk += (N + 31) // 32
         desc = torch.tensor(rows, dtype=torch.int64, device=self.dev)
         p.keep.append(desc)          # owned by the plan: a later rebuild of a D plan must not free what this one points at
-        p.add(self.L.colsum_multi, ptr(desc), len(rows), blk)
+        if opt is None:
+            p.add(self.L.colsum_multi, ptr(desc), len(rows), blk)
+        else:
+            fp, (state, inc0, inc1) = opt
+            p.add(self.L.colsum_multi_rmsprop, ptr(desc), len(rows), blk, ptr(fp.grad), ptr(fp.flat), ptr(fp.sq), fp.numel,
+                  self.lr, 0.99, 1e-8, state, inc0, inc1)
 
     def _grad_bucket_hook(self, p: Plan, which: str, stage: int):
         """Data parallel: all-reduce the flat gradient buffer in three buckets, each launched (asynchronously, on the
@@ -643,10 +655,15 @@ class TrainEngine:
         kin = 256 * Ls[4]
         observer_forward(p, df, self.fake_rows, self.ldx, 1, B, Y, PO, b["F1"], b["F2"], b["LOG"], self.ldc)
         p.join()                       # critic scores of the fake rows (side lane) are needed from here on
-        self._nsel_sync_hook(p)
-        p.add(self.L.masked_ce, ptr(b["LOG"]), self.ldc, B, self.C, ptr(b["labels"]), ptr(b["gV"]),
-              b["ghead"].data_ptr() + 4, self.alpha, ptr(b["CE"]), ptr(b["DLOG"]), self.ldc)
-        p.add(self.L.g_loss, ptr(b["CE"]), B, ptr(b["ghead"]), self.alpha, ptr(b["gstats"]), ptr(b["gacc"]))
+        if self.g_tail_fused:
+            # g_head + masked CE + G-step scalars as one single-workgroup launch (small batch, no all-reduce in between)
+            p.add(self.L.g_tail, ptr(b["LOG"]), self.ldc, B, self.C, ptr(b["labels"]), ptr(b["gV"]), 1.0 / self.Bg, self.alpha,
+                  ptr(b["CE"]), ptr(b["DLOG"]), self.ldc, ptr(b["ghead"]), ptr(b["gstats"]), ptr(b["gacc"]))
+        else:
+            self._nsel_sync_hook(p)
+            p.add(self.L.masked_ce, ptr(b["LOG"]), self.ldc, B, self.C, ptr(b["labels"]), ptr(b["gV"]),
+                  b["ghead"].data_ptr() + 4, self.alpha, ptr(b["CE"]), ptr(b["DLOG"]), self.ldc)
+            p.add(self.L.g_loss, ptr(b["CE"]), B, ptr(b["ghead"]), self.alpha, ptr(b["gstats"]), ptr(b["gacc"]))
         # ---- input gradient
         p.gemm_mul(NN, b["DLOG"], self.ldc, df.fc_w, 512, B, 512, self.C, b["F2"], 512, DM_RELU, df.fc2_scale, b["DF2"], 512)
         p.gemm_mul(NN, b["DF2"], 512, df.fc2_w, 512, B, 512, 512, b["F1"], 512, DM_RELU, df.fc1_scale, b["DF1"], 512)
@@ -679,7 +696,9 @@ class TrainEngine:
         ghead = self.buf["ghead"]
         p.host(lambda: self.comm.all_reduce_sum_(ghead), self.comm.capturable)
 
-    def _build_g_plan(self, fast: bool = False, draw_masks: bool = True) -> Plan:
+    def _build_g_plan(self, fast: bool = False, draw_masks: bool = True, bn_stacked: Optional[Dict[str, torch.Tensor]] = None) -> Plan:
+        """bn_stacked (GroupedTrainer): the [slots, N] statistics of the group's stacked generator forwards, whose
+        running-statistics updates were left to this plan: all slots' batches in order, the last one twice."""
         B, S, C, Z, b, G = self.B, self.S, self.C, self.Z, self.buf, self.Gp
         p = Plan(b["ws"], b["ws2"], self.overlap, self.gemm_mode, self.wk)
         st = self.iter_state.data_ptr()
@@ -688,16 +707,20 @@ class TrainEngine:
             p.add(self.L.rng_dropout_mask, ptr(t), t.numel(), 0.2, (self.seed + 4 * self.GOLD) & (2**64 - 1), st, 0)
         # The generator parameters and z are unchanged since the D-step's forward, so the second
         # generator(z, c) of :240 reproduces the same activations; only its BN running-stat update is new.
-        for i, bn, n in ((2, "model.3", 1024), (3, "model.6", 2048)):
-            p.add(self.L.bn_running_update, ptr(b[f"mean{i}"]), ptr(b[f"m2{i}"]), float(self.Bg), n,
-                  ptr(self.Gbuf[f"{bn}.running_mean"]), ptr(self.Gbuf[f"{bn}.running_var"]), 0.1, 1)
+        src = bn_stacked if bn_stacked is not None else b
+        groups = bn_stacked["mean2"].shape[0] if bn_stacked is not None else 1
+        p.add(self.L.bn_running_update_layers, ptr(src["mean2"]), ptr(src["m22"]), 1024,
+              ptr(self.Gbuf["model.3.running_mean"]), ptr(self.Gbuf["model.3.running_var"]), ptr(src["mean3"]), ptr(src["m23"]),
+              2048, ptr(self.Gbuf["model.6.running_mean"]), ptr(self.Gbuf["model.6.running_var"]), float(self.Bg), 0.1, groups,
+              2 if bn_stacked is not None else 1)
         # side lane: critic pass on the fake rows + its input-gradient chain (slabs stay in the side workspace until
         # g_out_bwd reads them); main lane: the DF observer forward.  They meet at the masked CE.
         p.fork()
         with p.side():
             self._critic_forward(p, self.fake_rows, B, (b["gMK1"], b["gMK2"], b["gMK3"]), b["gH1"], b["gH2"],
                                  b["gH3"], b["gD1"], b["gD2"], b["gD3"], b["gV"], b["gDL3"], None, None)
-            p.add(self.L.g_head, ptr(b["gV"]), B, 1.0 / self.Bg, ptr(b["ghead"]))
+            if not self.g_tail_fused:
+                p.add(self.L.g_head, ptr(b["gV"]), B, 1.0 / self.Bg, ptr(b["ghead"]))
             g = self._critic_chain(p, B, b["gDL3"], b["gDL2"], None, b["gDL1"], None, b["gD2"], b["gD1"], None)
         self._observer(p)
         if B > 512:      # tall batch: dz in one fully parallel pass, its column sums (the bias gradient) by row chunks
@@ -1193,7 +1216,8 @@ class GroupedTrainer:
         self.merged_masks = n + 1 <= 8          # one launch draws the dropout masks of the whole group (8 buffers at most)
         self.head = self._build_head()
         self.rest = [e._build_d_plan(fast=True, part="rest_draw", draw_masks=not self.merged_masks) for e in self.e]
-        self.gstep = self.e[n - 1]._build_g_plan(fast=True, draw_masks=not self.merged_masks)
+        # the running-statistics updates of the three stacked forwards ride on the G-step's own update launch
+        self.gstep = self.e[n - 1]._build_g_plan(fast=True, draw_masks=not self.merged_masks, bn_stacked=self.stacked)
         self.group = Plan(self.ws, gemm_mode=eng.gemm_mode, wk=eng.wk)
         self.group.extend(self.head)
         for r in self.rest:
@@ -1240,8 +1264,7 @@ class GroupedTrainer:
             s = p.gemm(NT, prev, kprev, G[f"{lin}.weight"], kprev, M, width, kprev)
             p.add(L.bn_train_relu_grouped, s.ptr, s.ns, s.ss, s.ldp, B, n, width, ptr(G[f"{lin}.bias"]), 0.8,
                   ptr(G[f"{bn}.weight"]), ptr(G[f"{bn}.bias"]), ptr(st[f"GXH{i}"]), ptr(st[f"GH{i}"]), width,
-                  ptr(st[f"mean{i}"]), ptr(st[f"m2{i}"]), ptr(st[f"istd{i}"]), ptr(eng.Gbuf[f"{bn}.running_mean"]),
-                  ptr(eng.Gbuf[f"{bn}.running_var"]), 0.1)
+                  ptr(st[f"mean{i}"]), ptr(st[f"m2{i}"]), ptr(st[f"istd{i}"]), 0, 0, 0.1)      # running statistics: see gstep
             prev, kprev = st[f"GH{i}"], width
         s = p.gemm(NT, prev, 2048, G["model.8.weight"], 2048, M, S, 2048)
         p.add(L.ep_sigmoid_lenmask_slots, s.ptr, s.ns, s.ss, s.ldp, M, S, ptr(G["model.8.bias"]), eng.range_f, eng.smin_f,
