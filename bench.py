@@ -225,6 +225,8 @@ def main():
     ap.add_argument("--fuse-opt", dest="fuse_opt", default="1", choices=["0", "1", "d", "g"],
                     help="1 (single GPU): RMSprop applied inside each weight gradient's store (wfd_gemm_f32_rmsprop), the "
                          "gradient never written; 0: gradient buffers + one flat optimizer pass (what data parallel runs)")
+    ap.add_argument("--observer-ahead", dest="observer_ahead", type=int, default=0,
+                    help="1: the DF observer's forward of a group runs on a side lane beside the group's critic updates")
     ap.add_argument("--force-dp", action="store_true",
                     help="one GPU: run the data-parallel code path (bucketed gradient all-reduce over a 1-rank RCCL group, "
                          "flat optimizer pass) to price its launch structure; WFD_DP_GRAPH=0 keeps the collectives out of the graphs")
@@ -251,7 +253,7 @@ def main():
     grouped = bool(args.grouped) and not strong and not pipelined
     if grouped:             # the generator forwards of the n_critic iterations sharing generator parameters run stacked
         from wfd_gan_amd.engine import GroupedTrainer
-        drv = GroupedTrainer(eng, graphs=not args.no_graph)
+        drv = GroupedTrainer(eng, graphs=not args.no_graph, observer_ahead=bool(args.observer_ahead))
         if not args.no_graph and args.steps % eng.n_critic:
             eng.capture_graphs()
     elif pipelined:         # generator forward of iteration i+1 on a second stream beside iteration i's critic update

@@ -167,3 +167,32 @@ def test_grouped_fast_mode_fused_equals_flat_pass(graphs):
     for k, (a, b) in enumerate(zip(*out)):
         assert torch.equal(a, b), f"tensor {k} differs between the fused and the flat optimizer path"
     assert torch.isfinite(out[0][0]).all() and float((out[0][0] != 0).float().mean()) > 0.5
+
+
+@pytest.mark.parametrize("graphs", [False, True])
+def test_grouped_observer_ahead_is_bit_identical(graphs):
+    """GroupedTrainer(observer_ahead=True): the DF observer's forward of a group runs on a side lane beside the group's
+    critic updates (it reads only the generated rows and the frozen observer).  Same kernels on the same inputs, only the
+    schedule differs: every state tensor must be bit-identical to the single-lane group after three groups."""
+    from wfd_gan_amd.engine import GroupedTrainer, TrainEngine
+    S, C, Z, B = 101, 6, 24, 16
+    X, y = O.synth_dataset(C, 30, S - 1, 10, 13, 122, seed=1)
+    dmin, dmax = X.min(0), X.max(0)
+    scale, min_ = O.scaler_params(dmin, dmax)
+    Xs = torch.from_numpy(X * scale + min_).float()
+    out = []
+    for ahead in (True, False):
+        st = O.make_state(S, C, Z, dmin[0], dmax[0], seed=2, df_seed=3)
+        O.perturb_df_bn(st.DF, 4)
+        eng = TrainEngine(S, C, Z, B, st.scaler_min, st.scaler_max, {k: v.detach() for k, v in st.G.items()},
+                          {k: v.detach() for k, v in st.D.items()}, st.DF, device=DEV, seed=11, fuse_opt=True)
+        eng.attach_dataset(Xs, torch.from_numpy(y), shuffle_seed=5)
+        grp = GroupedTrainer(eng, graphs=graphs, observer_ahead=ahead)
+        for _ in range(3):
+            grp.run_group()
+        torch.cuda.synchronize()
+        out.append([eng.Dp.flat.clone(), eng.Dp.sq.clone(), eng.Gp.flat.clone(), eng.Gp.sq.clone(), eng.iter_state.clone(),
+                    eng.buf["dacc"].clone(), eng.buf["gacc"].clone(), grp.slot(2).buf["LOG"].clone(),
+                    grp.slot(2).buf["DDF"].clone()] + [v.clone() for v in eng.Gbuf.values()])
+    for k, (a, b) in enumerate(zip(*out)):
+        assert torch.equal(a, b), f"tensor {k} differs between the two schedules"

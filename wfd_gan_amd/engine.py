@@ -553,7 +553,8 @@ class TrainEngine:
             (b["V"], 1, b["RSELF"], None, 0, None, M, 1, b["dstats"][4:5])], opt=(D, st_arg) if self.fuse_d else None)
         if self.fuse_d:
             return p
-        p.join()
+        if self.overlap:
+            p.join()
         self._grad_sync_hook(p, "D")
         self._optimizer(p, D, False, *st_arg)
         return p
@@ -647,13 +648,19 @@ class TrainEngine:
     def _grad_sync_hook(self, p: Plan, which: str):
         self._grad_bucket_hook(p, which, 2)
 
-    def _observer(self, p: Plan):
-        """DF forward on fake[:, 1:], masked CE, and the input gradient dDF (src/mlp_df_wgan_train.py:251-263,273)."""
+    def _observer_forward(self, p: Plan):
+        b = self.buf
+        observer_forward(p, self.df, self.fake_rows, self.ldx, 1, self.B, b["Y"], b["PO"], b["F1"], b["F2"], b["LOG"], self.ldc)
+
+    def _observer(self, p: Plan, forward: bool = True):
+        """DF forward on fake[:, 1:], masked CE, and the input gradient dDF (src/mlp_df_wgan_train.py:251-263,273).
+        forward = False: the forward already ran (GroupedTrainer issues it beside the group's critic updates)."""
         B, b, df = self.B, self.buf, self.df
         Ls, Y, PO, DC, DPO = df.Ls, b["Y"], b["PO"], b["DC"], b["DPO"]
         cv = df.convs
         kin = 256 * Ls[4]
-        observer_forward(p, df, self.fake_rows, self.ldx, 1, B, Y, PO, b["F1"], b["F2"], b["LOG"], self.ldc)
+        if forward:
+            self._observer_forward(p)
         p.join()                       # critic scores of the fake rows (side lane) are needed from here on
         if self.g_tail_fused:
             # g_head + masked CE + G-step scalars as one single-workgroup launch (small batch, no all-reduce in between)
@@ -696,11 +703,12 @@ class TrainEngine:
         ghead = self.buf["ghead"]
         p.host(lambda: self.comm.all_reduce_sum_(ghead), self.comm.capturable)
 
-    def _build_g_plan(self, fast: bool = False, draw_masks: bool = True, bn_stacked: Optional[Dict[str, torch.Tensor]] = None) -> Plan:
+    def _build_g_plan(self, fast: bool = False, draw_masks: bool = True, bn_stacked: Optional[Dict[str, torch.Tensor]] = None,
+                      observer_forward: bool = True, plan: Optional[Plan] = None) -> Plan:
         """bn_stacked (GroupedTrainer): the [slots, N] statistics of the group's stacked generator forwards, whose
         running-statistics updates were left to this plan: all slots' batches in order, the last one twice."""
         B, S, C, Z, b, G = self.B, self.S, self.C, self.Z, self.buf, self.Gp
-        p = Plan(b["ws"], b["ws2"], self.overlap, self.gemm_mode, self.wk)
+        p = plan if plan is not None else Plan(b["ws"], b["ws2"], self.overlap, self.gemm_mode, self.wk)
         st = self.iter_state.data_ptr()
         if fast and draw_masks:
             t = b["gMKflat"]
@@ -715,14 +723,15 @@ class TrainEngine:
               2 if bn_stacked is not None else 1)
         # side lane: critic pass on the fake rows + its input-gradient chain (slabs stay in the side workspace until
         # g_out_bwd reads them); main lane: the DF observer forward.  They meet at the masked CE.
-        p.fork()
-        with p.side():
+        if observer_forward:
+            p.fork()
+        with p.side(stream=observer_forward):       # the slabs of g stay in the side workspace either way
             self._critic_forward(p, self.fake_rows, B, (b["gMK1"], b["gMK2"], b["gMK3"]), b["gH1"], b["gH2"],
                                  b["gH3"], b["gD1"], b["gD2"], b["gD3"], b["gV"], b["gDL3"], None, None)
             if not self.g_tail_fused:
                 p.add(self.L.g_head, ptr(b["gV"]), B, 1.0 / self.Bg, ptr(b["ghead"]))
             g = self._critic_chain(p, B, b["gDL3"], b["gDL2"], None, b["gDL1"], None, b["gD2"], b["gD1"], None)
-        self._observer(p)
+        self._observer(p, forward=observer_forward)
         if B > 512:      # tall batch: dz in one fully parallel pass, its column sums (the bias gradient) by row chunks
             part = b.setdefault("gout_part", torch.zeros(((B + 127) // 128) * S, dtype=torch.float32, device=self.dev))
             p.add(self.L.g_out_bwd, g.ptr, g.ns, g.ss, g.ldp, B, S, -1.0 / self.Bg, ptr(b["DDF"]), self.ldl,
@@ -766,7 +775,8 @@ class TrainEngine:
         p.add(self.L.colsum, ptr(b["GDZ1"]), 512, B, 512, 0, ptr(G.g["model.0.bias"]), 0)
         p.gemm(TN, b["GDZ1"], 512, b["ZIN"], self.ldz, 512, Z + C, B, out=G.g["model.0.weight"],
                ldp=G.ld["model.0.weight"])
-        p.join()
+        if self.overlap:
+            p.join()
         self._grad_sync_hook(p, "G")
         self._optimizer(p, G, False, st if fast else 0, self._rng_inc() if fast else 0, 0)
         return p
@@ -1191,7 +1201,11 @@ class GroupedTrainer:
     head buffers are views of the stacked tensors), so the critic update, the penalty and the G-step are the
     sequential engine's plans unchanged; arithmetic and the order of every state update are the reference's."""
 
-    def __init__(self, eng: "TrainEngine", graphs: bool = True):
+    def __init__(self, eng: "TrainEngine", graphs: bool = True, observer_ahead: bool = False):
+        """observer_ahead: the frozen DF observer's forward on the last slot's generated rows depends on nothing the group's
+        critic updates write, so it is issued on a side lane (second stream / graph branch) right after the stacked heads
+        and joins the main lane at the G-step's masked cross-entropy."""
+        self.observer_ahead = bool(observer_ahead)
         if eng.exact:
             raise ValueError("the grouped driver does not cover the SyncBN mode (collectives inside the generator forward)")
         if not hasattr(eng, "data_X"):
@@ -1217,9 +1231,24 @@ class GroupedTrainer:
         self.head = self._build_head()
         self.rest = [e._build_d_plan(fast=True, part="rest_draw", draw_masks=not self.merged_masks) for e in self.e]
         # the running-statistics updates of the three stacked forwards ride on the G-step's own update launch
-        self.gstep = self.e[n - 1]._build_g_plan(fast=True, draw_masks=not self.merged_masks, bn_stacked=self.stacked)
-        self.group = Plan(self.ws, gemm_mode=eng.gemm_mode, wk=eng.wk)
+        last = self.e[n - 1]
+        if self.observer_ahead:
+            # lanes: main = critic updates + G-step, side = observer forward (own slab workspace)
+            mk = lambda: Plan(last.buf["ws"], last.buf["ws2"], True, eng.gemm_mode, eng.wk)
+            self.obs = mk()
+            self.obs.fork()
+            with self.obs.side():
+                last._observer_forward(self.obs)
+            self.gstep = last._build_g_plan(fast=True, draw_masks=not self.merged_masks, bn_stacked=self.stacked,
+                                            observer_forward=False, plan=mk())
+            self.group = Plan(self.ws, last.buf["ws2"], True, eng.gemm_mode, eng.wk)
+        else:
+            self.obs = None
+            self.gstep = last._build_g_plan(fast=True, draw_masks=not self.merged_masks, bn_stacked=self.stacked)
+            self.group = Plan(self.ws, gemm_mode=eng.gemm_mode, wk=eng.wk)
         self.group.extend(self.head)
+        if self.obs is not None:
+            self.group.extend(self.obs)
         for r in self.rest:
             self.group.extend(r)
         self.group.extend(self.gstep)

@@ -60,16 +60,17 @@ class Plan:
         # device tensors that only this plan's launches reference by raw pointer (descriptor tables): they live as long as
         # the plan (and any plan it is concatenated into, and the graphs captured from it, which keep the plan alive)
         self.keep: List[torch.Tensor] = []
-        self.lane = 0
+        self.lane = 0                                  # stream lane of the launches being added
+        self.wsl = 0                                   # lane whose slab workspace they use
         self.overlap = self.two and overlap            # side lane on its own stream (else: same stream, in order)
 
     @property
     def ws(self):
-        return self.ws_lane[self.lane]
+        return self.ws_lane[self.wsl]
 
     @property
     def ws_floats(self):
-        return self.ws_lane[self.lane].numel()
+        return self.ws_lane[self.wsl].numel()
 
     def pick_splits(self, M: int, N: int, K: int) -> int:
         return self.L.gemm_pick_splits_mode(M, N, K, self.gemm_mode)
@@ -101,19 +102,24 @@ class Plan:
             self.calls.append((JOIN, (), 1))
 
     class _Side:
-        def __init__(self, plan):
-            self.plan = plan
+        def __init__(self, plan, stream):
+            self.plan, self.stream = plan, stream
 
         def __enter__(self):
             if self.plan.two:
-                self.plan.lane = 1
+                self.plan.wsl = 1
+                if self.stream:
+                    self.plan.lane = 1
 
         def __exit__(self, *exc):
             self.plan.lane = 0
+            self.plan.wsl = 0
 
-    def side(self):
-        """``with plan.side(): ...`` issues the enclosed launches on the side lane (no-op without overlap)."""
-        return Plan._Side(self)
+    def side(self, stream: bool = True):
+        """``with plan.side(): ...`` issues the enclosed launches on the side lane with the side lane's slab workspace (the
+        stream part is a no-op without overlap).  stream = False: the side WORKSPACE only (slabs that must outlive later
+        main-lane products), launches stay on the main lane."""
+        return Plan._Side(self, stream)
 
     def run(self, serial: bool = False):
         prev = self.L.get_gemm_mode()
