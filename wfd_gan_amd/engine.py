@@ -1204,7 +1204,11 @@ class GroupedTrainer:
     def __init__(self, eng: "TrainEngine", graphs: bool = True, observer_ahead: bool = False):
         """observer_ahead: the frozen DF observer's forward on the last slot's generated rows depends on nothing the group's
         critic updates write, so it is issued on a side lane (second stream / graph branch) right after the stacked heads
-        and joins the main lane at the G-step's masked cross-entropy."""
+        and joins the main lane at the G-step's masked cross-entropy.  Bit-identical to the single-lane group
+        (tests/test_gpu_fused_opt.py).  MEASURED (round 2, one MI355X, config 2, same session): 3010 vs 3075 it/s -- and moving
+        the observer's backward to the branch as well (unit row weights, applied afterwards) gave the same 3015 vs 3080: a
+        second branch in a HIP graph does not overlap with the first on this stack, it only adds the fork / join.  Off by
+        default; kept as the measured record (bench.py --observer-ahead 1)."""
         self.observer_ahead = bool(observer_ahead)
         if eng.exact:
             raise ValueError("the grouped driver does not cover the SyncBN mode (collectives inside the generator forward)")
@@ -1234,8 +1238,11 @@ class GroupedTrainer:
         last = self.e[n - 1]
         if self.observer_ahead:
             # lanes: main = critic updates + G-step, side = observer forward (own slab workspace)
+            # (own slab workspace for the observer lane: the G-step's critic pass keeps its input-gradient slabs in the engine's
+            # side workspace, and may run while the observer still does)
+            self.ws_obs = torch.empty(max(eng.B * eng.S * 64, 1 << 20), dtype=torch.float32, device=dev)
             mk = lambda: Plan(last.buf["ws"], last.buf["ws2"], True, eng.gemm_mode, eng.wk)
-            self.obs = mk()
+            self.obs = Plan(last.buf["ws"], self.ws_obs, True, eng.gemm_mode, eng.wk)
             self.obs.fork()
             with self.obs.side():
                 last._observer_forward(self.obs)
