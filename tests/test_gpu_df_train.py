@@ -181,3 +181,40 @@ def test_train_df_cli_learns(tmp_path):
     ts = generate.TraceSampler(os.path.join(run, "model"), device=DEV, chunk=64, mode="wt")
     outs, lens = ts.sample_many(torch.arange(64) % n_cls)
     assert outs.shape == (64, L + 1) and bool((lens % 2 == 0).all())
+
+
+@pytest.mark.parametrize("name", ["tiny", "cfg"])
+def test_df_train_trajectory_without_parameter_resets(name):
+    """Multi-step drift of the observer's trainer: the fixture's batches, cycled for 8 Adamax steps, with NO reset of the
+    engine's parameters to the oracle's in between (the per-step test above resets them).  The first Adamax steps move every
+    element by ~lr whatever |g| is, so two fp32 trajectories part wherever a gradient is rounding noise; the reference's own
+    sensitivity to that is measured here as the distance between the oracle run in fp32 and in fp64.  Stated tolerance:
+    the loss of every step within 1e-3 relative of the fp32 oracle's + four times that fp32-vs-fp64 distance at the step
+    (two fp32 runs sit on either side of the fp64 one; measured worst case: 0.43 of the tolerance at L = 1400, batch 128)."""
+    from wfd_gan_amd.df_engine import DFTrainEngine
+    fx = np.load(os.path.join(GOLDEN, f"df_train_{name}.npz"))
+    meta = json.loads(str(fx["meta"]))
+    L, C, B = meta["length"], meta["class_dim"], meta["batch"]
+    torch.manual_seed(meta["seed"])
+    sd0 = O.make_df_state(L, C)
+    eng = DFTrainEngine(L, C, B, sd0, device=DEV)
+    ref = DT.DFTrainer(sd0)
+    ref64 = DT.DFTrainer({k: (v.double() if v.is_floating_point() else v) for k, v in sd0.items()})
+    shapes = DT.dropout_mask_shapes(L, B)
+    worst, losses = 0.0, []
+    for it in range(8):
+        p = f"it{it % meta['n_steps']}_"
+        x, y = torch.from_numpy(fx[p + "x"]), torch.from_numpy(fx[p + "y"])
+        masks = _masks(fx, p, shapes)
+        want = ref.step(x[:, None, :], y, masks=masks)["loss"]
+        exact = ref64.step(x.double()[:, None, :], y, masks=[m.double() for m in masks])["loss"]
+        eng.set_batch(x, y)
+        eng.set_masks(masks)
+        eng.train_step()
+        torch.cuda.synchronize()
+        tol = RTOL * abs(want) + 4 * abs(want - exact)
+        worst = max(worst, abs(eng.loss() - want) / tol)
+        losses.append(eng.loss())
+        assert abs(eng.loss() - want) <= tol, (it, eng.loss(), want, exact)
+    print(f"df-train trajectory[{name}]: worst |got - want| / tolerance = {worst:.3f}; losses {['%.4f' % v for v in losses]}")
+    assert np.isfinite(losses).all()

@@ -224,3 +224,52 @@ def test_trainer_and_sampler_cli(tmp_path):
     generate.main(["-m", os.path.join(out, "model"), "--n", "300", "--chunk", "128", "--out", str(tmp_path / "t.npz")])
     t = np.load(str(tmp_path / "t.npz"))
     assert t["traces"].shape == (300, 41) and t["lens"].shape == (300,)
+
+
+@pytest.mark.parametrize("penalty", ["gp", "div"])
+def test_trajectory_without_parameter_resets(penalty):
+    """Multi-step drift: 6 iterations (G-steps at 0 and 3) with NO reset of the engine's parameters to the oracle's bits in
+    between (the per-iteration gradient tests above reset them so that a LeakyReLU coin flip does not turn into a gradient
+    mismatch).  Every loss scalar of the trajectory must stay within 1e-3 relative (+ the absolute floors of test_gpu_step)
+    of the fp32 oracle's, plus twice the oracle's own fp32-vs-fp64 distance at that iteration -- the reference's own
+    trajectory noise, which is what a different but equally valid fp32 summation order may pick up."""
+    S, C, Z, B = 501, 10, 64, 32
+    st, eng, Xs, y = _setup(S, C, Z, B, penalty, seed=6)
+    st64 = O.make_state(S, C, Z, st.scaler_min, st.scaler_max, seed=6, df_seed=7, penalty=penalty, dtype=torch.float64)
+    g = torch.Generator().manual_seed(2)
+    perm = torch.randperm(Xs.shape[0], generator=g)
+    worst = 0.0
+    for it in range(6):
+        idx = perm[torch.arange(it * B, (it + 1) * B) % perm.numel()].numpy()
+        traces, labels = torch.from_numpy(Xs[idx]), torch.from_numpy(y[idx])
+        z = torch.randn(B, Z, generator=g)
+        alpha = torch.rand(B, 1, generator=g)
+        mk = lambda: [(torch.rand(B, n, generator=g) > 0.2).float() * 1.25 for n in (2048, 1024, 512)]
+        mr, mf, mgp, mg = mk(), mk(), mk(), mk()
+        do_g = it % 3 == 0
+        kw = dict(gp_alpha=alpha, masks_gp=mgp) if penalty == "gp" else {}
+        d64 = lambda ms: [t.double() for t in ms]
+        kw64 = dict(gp_alpha=alpha.double(), masks_gp=d64(mgp)) if penalty == "gp" else {}
+        ref = O.iteration(st, traces, labels, z, do_g, mr, mf, mg, keep=True, **kw)
+        ex = O.iteration(st64, traces.double(), labels, z.double(), do_g, d64(mr), d64(mf), d64(mg), keep=True, **kw64)
+        eng.set_batch(traces, labels, z)
+        if penalty == "gp":
+            eng.set_gp_alpha(alpha)
+            eng.set_masks([torch.cat([a, b, c]) for a, b, c in zip(mr, mf, mgp)], mg)
+        else:
+            eng.set_masks([torch.cat([a, b]) for a, b in zip(mr, mf)], mg)
+        eng.d_step()
+        if do_g:
+            eng.g_step()
+        torch.cuda.synchronize()
+        d = eng.d_stats()
+        got = dict(d)
+        if do_g:
+            got.update(eng.g_stats())
+        for k, atol in (("penalty", 0.0), ("d_loss", 4e-5), ("w_dist", 4e-5), ("mean_rv", 2e-5), ("mean_fv", 2e-5)) + \
+                ((("g_loss", 2e-5),) if do_g else ()):
+            want, exact = float(ref[k]), float(ex[k])
+            tol = 1e-3 * abs(want) + atol + 2 * abs(want - exact)
+            worst = max(worst, abs(got[k] - want) / max(tol, 1e-30))
+            assert abs(got[k] - want) <= tol, (penalty, it, k, got[k], want, exact)
+    print(f"trajectory[{penalty}]: worst |got - want| / tolerance = {worst:.3f}")
