@@ -341,6 +341,34 @@ def main():
                               "unit": "TFLOP/s", "frac": tps / world * 2.0 * G_MAC / 1e12 / PEAK_F32_MFMA_TFLOPS,
                               "flops_per_trace": 2.0 * G_MAC,
                               "note": "whole sampler chunk (4 contractions + epilogues) per GPU against the f32-input MFMA peak"})
+        # the same chunks with the int32 burst vectors and lengths copied to (pinned) host memory, copy of chunk i overlapped with
+        # the generation of chunk i + 1 (two device staging buffers, a copy stream): the PCIe-inclusive rate, reported beside
+        # `value`, never as it
+        host = [torch.empty((chunk, args.seq_len), dtype=torch.int32).pin_memory() for _ in range(2)]
+        hlen = [torch.empty(chunk, dtype=torch.int32).pin_memory() for _ in range(2)]
+        stage = [torch.empty_like(bs.out) for _ in range(2)]
+        stlen = [torch.empty_like(bs.lens) for _ in range(2)]
+        cs = torch.cuda.Stream(device=device)
+        main = torch.cuda.current_stream()
+        done = [None, None]
+        barrier()
+        t1 = time.perf_counter()
+        for i in range(nchunks):
+            k = i & 1
+            bs.run_chunk(labels)
+            if done[k] is not None:
+                main.wait_event(done[k])            # the staging buffer's previous copy has left
+            stage[k].copy_(bs.out); stlen[k].copy_(bs.lens)
+            ev = torch.cuda.Event(); ev.record(main)
+            cs.wait_event(ev)
+            with torch.cuda.stream(cs):
+                host[k].copy_(stage[k], non_blocking=True); hlen[k].copy_(stlen[k], non_blocking=True)
+                done[k] = torch.cuda.Event(); done[k].record(cs)
+        cs.synchronize()
+        barrier()
+        samp["d2h_inclusive_traces_per_s"] = world * nchunks * chunk / parallel.max_over_ranks(time.perf_counter() - t1, device)
+        samp["d2h_bytes_per_trace"] = 4 * args.seq_len + 4
+        del host, hlen, stage, stlen
         # same sampler with bf16-operand MFMA (not the parity path; tolerance in tests/test_gpu_bf16.py)
         bs16 = BulkSampler(eng.generator_state(), args.seq_len, args.classes, args.latent_dim, dmin, dmax, chunk=chunk,
                            device=device, seed=99 + rank, operands="bf16")
