@@ -130,3 +130,68 @@ def test_wk_conv8_matches_torch(geom, cfg):
                    scd.data_ptr(), shd.data_ptr(), 2, 0, 0, 0, cfg, st)
     torch.cuda.synchronize()
     assert (out.double().cpu() - want).abs().max().item() < 3e-6 * max(1.0, ref.abs().max().item())
+
+
+@pytest.mark.parametrize("mode", [1, 2])
+@pytest.mark.parametrize("cfg", [1, 2, 3, 4, 5])
+@pytest.mark.parametrize("layout", [0, 1])
+@pytest.mark.parametrize("shape", [(128, 2048, 1501), (64, 512, 600), (5, 7, 33), (33, 100, 512)])
+def test_wk_bf16_pipe_modes(shape, layout, cfg, mode):
+    """The same kernel with its fragments converted to bf16 (mode 1) / split-bf16 hi + lo (mode 2, three MFMAs per product)
+    on their way out of LDS: gemm_mx.hip's arithmetic.  Stated tolerances against fp64: bf16 operands 2e-2 of the largest
+    entry (2^-9 per operand over a random-sign contraction), split-bf16 1e-4 (products ~1e-5 relative); the fused
+    LeakyReLU + dropout store is exercised in both."""
+    L, st = _L()
+    M, N, K = shape
+    A, lda, B, ldb, ref, g = _operands(layout, M, N, K, seed=M + N + K + layout)
+    scale_k = ref.abs().max().item()
+    tol = {1: 2e-2, 2: 1e-4}[mode] * scale_k
+    ldo = rup(N)
+    out = torch.full((M, ldo), float("nan"), device=DEV)
+    shift = torch.randn(N, generator=g)
+    mask = (torch.rand(M, N, generator=g) > 0.2).float() * 1.25
+    shd, md = shift.to(DEV), mask.to(DEV)
+    o1, o2 = torch.full((M, ldo), float("nan"), device=DEV), torch.full((M, ldo), float("nan"), device=DEV)
+    L.set_gemm_mode(mode)
+    try:
+        L.gemm_f32_wk(layout, A.data_ptr(), lda, B.data_ptr(), ldb, M, N, K, 0, out.data_ptr(), ldo, 0, 0, 0, 0, 0, 0, 0, 0, 0,
+                      0, 0, 0.0, cfg, st)
+        L.gemm_f32_wk(layout, A.data_ptr(), lda, B.data_ptr(), ldb, M, N, K, 3, o1.data_ptr(), ldo, o2.data_ptr(), ldo, 0,
+                      shd.data_ptr(), 0, 0, 0, 0, 0, md.data_ptr(), N, 0.2, cfg, st)
+        torch.cuda.synchronize()
+    finally:
+        L.set_gemm_mode(0)
+    assert (out[:, :N].double().cpu() - ref).abs().max().item() < tol
+    if ldo > N:
+        assert torch.isnan(out[:, N:]).all()
+    z = ref + shift.double()
+    assert (o1[:, :N].double().cpu() - F.leaky_relu(z, 0.2) * mask.double()).abs().max().item() < 1.25 * tol
+    sure = z.abs() > 2 * tol
+    dd = mask.double() * torch.where(z > 0, 1.0, 0.2)
+    assert ((o2[:, :N].double().cpu() - dd).abs() * sure).max().item() < 1e-6
+
+
+@pytest.mark.parametrize("mode", [1, 2])
+@pytest.mark.parametrize("geom", [(3, 175, 32, 64, 3), (5, 3, 128, 256, 3), (2, 40, 64, 32, 4)])
+def test_wk_conv8_bf16_pipe_modes(geom, mode):
+    L, st = _L()
+    Bn, Ln, Cin, Cout, pad = geom
+    g = torch.Generator().manual_seed(Bn * 100 + Ln + Cin)
+    X = torch.randn(Bn, Ln, Cin, generator=g)
+    W = torch.randn(Cout, Cin, 8, generator=g) * 0.1
+    scale, shift = torch.rand(Cout, generator=g) + 0.5, torch.randn(Cout, generator=g)
+    Wp = W.permute(0, 2, 1).reshape(Cout, 8 * Cin).contiguous()
+    xp = F.pad(X.permute(0, 2, 1).double(), (pad, 7 - pad))
+    ref = F.conv1d(xp, W.double()).permute(0, 2, 1).reshape(Bn * Ln, Cout)
+    want = F.elu(ref * scale.double() + shift.double())
+    out = torch.full((Bn * Ln, Cout), float("nan"), device=DEV)
+    Xd, Wd, scd, shd = X.to(DEV), Wp.to(DEV), scale.to(DEV), shift.to(DEV)
+    L.set_gemm_mode(mode)
+    try:
+        L.conv8_f32_wk(Xd.data_ptr(), Bn, Ln, Cin, pad, Wd.data_ptr(), Cout, 1, out.data_ptr(), Cout,
+                       scd.data_ptr(), shd.data_ptr(), 2, 0, 0, 0, 1, st)
+        torch.cuda.synchronize()
+    finally:
+        L.set_gemm_mode(0)
+    tol = {1: 2e-2, 2: 1e-4}[mode] * 1.5 * max(1.0, ref.abs().max().item())
+    assert (out.double().cpu() - want).abs().max().item() < tol

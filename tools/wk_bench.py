@@ -9,6 +9,8 @@ from wfd_gan_amd._lib import lib
 
 L = lib()
 dev = "cuda:0"
+MODE = int(sys.argv[1]) if len(sys.argv) > 1 else 0          # operand mode: 0 f32, 1 bf16, 2 bf16x3 (wfd_set_gemm_mode)
+L.set_gemm_mode(MODE)
 shapes = [  # (name, layout, M, N, K, lda, ldb)
     ("D fwd1 NT", 0, 128, 2048, 1501, 1504, 1504), ("D fwd2 NT", 0, 128, 1024, 2048, 2048, 2048),
     ("D fwd3 NT", 0, 128, 512, 1024, 1024, 1024), ("chain3 NN", 1, 128, 1024, 512, 512, 1024),
@@ -56,7 +58,7 @@ for name, lay, M, N, K, lda, ldb in shapes:
     bias = torch.randn(N, device=dev)
     mask = torch.ones(M, N, device=dev)
     H, D = torch.zeros(M, ldp, device=dev), torch.zeros(M, ldp, device=dev)
-    ns = L.gemm_pick_splits(M, N, K)
+    ns = L.gemm_pick_splits_mode(M, N, K, MODE)
 
     def old():
         st = torch.cuda.current_stream().cuda_stream

@@ -1,0 +1,93 @@
+#!/usr/bin/env python3
+"""In-step tuning of the split-inside-the-workgroup configuration per product: coordinate descent over the products of one
+group of the config-2 step, each candidate timed as the WHOLE step (graph replay of 50 groups) in the same process, because
+isolated per-kernel timings (tools/wk_bench.py) mispredict the step (cold weights, neighbours).  GPU only.
+
+    python tools/wk_tune.py [--operands f32] [--min-gain 0.003]
+"""
+import argparse, json, os, sys, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+import bench
+from wfd_gan_amd import plan as P
+from wfd_gan_amd.engine import GroupedTrainer
+
+ap = argparse.ArgumentParser()
+ap.add_argument("--operands", default="f32")
+ap.add_argument("--min-gain", type=float, default=0.003)
+ap.add_argument("--groups", type=int, default=60)
+ap.add_argument("--out", default="gpurun_out/wk_tune.json")
+a = ap.parse_args()
+args = argparse.Namespace(seq_len=1401, classes=100, latent_dim=500, batch=64, inst=1000, penalty="div", overlap=0, dp="weak",
+                          operands=a.operands, fuse_opt="1", wk=1, force_dp=False)
+dev = torch.device("cuda:0")
+mode = {"f32": 0, "bf16": 1, "bf16x3": 2}[a.operands]
+
+
+def measure(reps=3):
+    eng, _ = bench.build_engine(args, 0, 1, dev)
+    drv = GroupedTrainer(eng, graphs=True)
+    for _ in range(10):
+        drv.run_group()
+    best = 1e9
+    for _ in range(reps):
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(a.groups):
+            drv.run_group()
+        torch.cuda.synchronize()
+        best = min(best, (time.perf_counter() - t0) / a.groups)
+    shapes = []
+    L = eng.L
+    for fn, ar, _ in drv.group.calls:
+        if fn is L.gemm_f32_wk:
+            shapes.append((ar[0], ar[5], ar[6], ar[7]))
+        elif fn is L.conv8_f32_wk:
+            shapes.append((3, ar[1] * ar[2], ar[6], 8 * ar[3]))
+        elif fn is L.gemm_f32 and ar[0] in (0, 1):
+            shapes.append((ar[0], ar[8], ar[9], ar[10]))
+        elif fn is L.conv8_gemm_f32 or fn is L.conv8_gemm_f32_fused:
+            shapes.append((3, ar[1] * ar[2], ar[6], 8 * ar[3]))
+    del drv, eng
+    torch.cuda.empty_cache()
+    return best * 1e6, shapes
+
+
+base, shapes = measure()
+uniq = []
+for s in shapes:
+    if s not in uniq:
+        uniq.append(s)
+print(f"baseline {base:.1f} us per group, {len(uniq)} distinct products", flush=True)
+log = dict(baseline_us=base, steps=[])
+cur = base
+from wfd_gan_amd._lib import lib
+Lb = lib()
+for s in uniq:
+    pick = Lb.gemm_wk_pick(*s)
+    cands = [c for c in ((1, 5, 3, 4, 0) if s[0] == 3 else (1, 2, 3, 4, 5, 0)) if c != pick]
+    res = {}
+    for c in cands:
+        P.WK_OVERRIDE[s] = c
+        try:
+            res[c], _ = measure(reps=2)
+        except Exception as e:          # a configuration the shape cannot run
+            res[c] = float("inf")
+    bc = min(res, key=res.get)
+    line = dict(shape=s, pick=pick, base_us=cur, cands=res)
+    if res[bc] < cur * (1 - a.min_gain):
+        P.WK_OVERRIDE[s] = bc
+        again, _ = measure(reps=3)          # confirm
+        if again < cur * (1 - a.min_gain / 2):
+            cur = again
+            line["chosen"] = bc
+        else:
+            del P.WK_OVERRIDE[s]
+    else:
+        del P.WK_OVERRIDE[s]
+    log["steps"].append(line)
+    print(json.dumps(line), flush=True)
+log["final_us"] = cur
+log["override"] = {",".join(map(str, k)): v for k, v in P.WK_OVERRIDE.items()}
+json.dump(log, open(a.out, "w"), indent=1)
+print("final", cur, log["override"], flush=True)

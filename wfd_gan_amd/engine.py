@@ -330,7 +330,9 @@ class TrainEngine:
         # fast mode, data parallel: all ranks hold the same permutation; rank r takes rows [r*B, (r+1)*B) of each
         # run of B*world indices and the cursor advances by the rows all ranks consumed
         self.g_tail_fused = not self.exact and B <= 256
-        fuse = bool(self.fuse_opt) and not self.dp and not overlap
+        # (f32 operand mode only: the bf16-pipe core applies the update with the parameter loads inside its store, which costs
+        # more than the flat pass saves -- measured 2743 vs 3076 it/s in bf16x3 mode)
+        fuse = bool(self.fuse_opt) and not self.dp and not overlap and self.gemm_mode == 0
         # the weight gradients contract over 2 M (critic) / B (generator) rows: unsplit below 1024 (Plan.gemm)
         self.fuse_d = fuse and self.fuse_opt != "g" and 2 * M < 1024
         self.fuse_g = fuse and self.fuse_opt != "d" and B < 1024

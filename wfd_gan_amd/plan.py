@@ -35,6 +35,12 @@ def rup(x: int, m: int) -> int:
     return (x + m - 1) // m * m
 
 
+# Tuning hook (tools/wk_tune.py): {(layout, M, N, K): cfg} consulted before the library's own choice of the
+# split-inside-the-workgroup configuration (layout 3 = conv: M = rows, N = Cout, K = 8 Cin); cfg 0 = the slab form.  Empty in
+# production: the measured choices live in wfd_gemm_wk_pick.
+WK_OVERRIDE = {}
+
+
 class Plan:
     """Accumulates (function, args, lane) triples; ``run()`` launches them in order.
 
@@ -49,8 +55,8 @@ class Plan:
                  gemm_mode: int = 0, wk: bool = True):
         self.L = lib()
         # wk: small-batch products run with the K split inside the workgroup and their consumer fused into the store
-        # (wfd_gemm_f32_wk: one launch, no slabs) wherever the library picks that form; f32 operand mode only
-        self.wk = bool(wk) and int(gemm_mode) == 0
+        # (wfd_gemm_f32_wk: one launch, no slabs) wherever the library picks that form, in every operand mode
+        self.wk = bool(wk)
         # operand mode of the plan's contractions (include/wfdgan.h, wfd_set_gemm_mode): 0 f32-input MFMA (parity path),
         # 1 bf16 operands, 2 split-bf16 x3.  Set around run(), so plans of different modes can coexist in a process.
         self.gemm_mode = int(gemm_mode)
@@ -188,6 +194,8 @@ class Plan:
             return 0
         if ptr(A) % 16 or ptr(B) % 16 or lda % 4 or ldb % 4:
             return 0
+        if (layout, M, N, K) in WK_OVERRIDE:
+            return WK_OVERRIDE[(layout, M, N, K)]
         return self.L.gemm_wk_pick(layout, M, N, K)
 
     def _wk(self, layout, A, lda, B, ldb, M, N, K, cfg, epi, out, ldo, out2=None, ldo2=0, scale=None, shift=None, act=0,
@@ -323,6 +331,8 @@ class Plan:
     def conv_wk_cfg(self, X, Wp, M: int, Cin: int, Cout: int) -> int:
         if not self.wk or Cin % 32 or ptr(X) % 16 or ptr(Wp) % 16 or self.L.conv8_direct_mode(M, Cin, Cout, self.gemm_mode):
             return 0
+        if (3, M, Cout, 8 * Cin) in WK_OVERRIDE:
+            return WK_OVERRIDE[(3, M, Cout, 8 * Cin)]
         return self.L.gemm_wk_pick(3, M, Cout, 8 * Cin)
 
     def conv8_affine(self, X, Bn, L, Cin, pad, Wp, Cout, scale, shift, act, out):
