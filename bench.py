@@ -106,7 +106,7 @@ def gemm_roofline(eng, plans=None, rep=16, rounds=3):
     L = eng.L
     gemm_fns = {L.gemm_f32: "gemm", L.conv8_gemm_f32: "conv", L.gemm_f32_fused: "gemm_fused",
                 L.conv8_gemm_f32_fused: "conv", L.gemm_f32_pair: "pair", L.gemm_f32_wk: "gemm_wk", L.conv8_f32_wk: "conv",
-                L.gemm_f32_rmsprop: "gemm_rms"}
+                L.gemm_f32_rmsprop: "gemm_rms", L.gemm_f32_rmsprop_multi: "rms_multi"}
     calls = []
     for plan, weight in (plans or ((eng.fast_d, eng.n_critic), (eng.fast_g, 1))):
         for fn, a, _lane in plan.calls:
@@ -114,6 +114,10 @@ def gemm_roofline(eng, plans=None, rep=16, rounds=3):
                 continue
             kind = gemm_fns.get(fn)
             if kind is None:
+                continue
+            if kind == "rms_multi":      # several weight gradients in one launch: their FLOPs add
+                w = a[0]
+                calls.append((fn, a, sum(2.0 * w[10 * k + 4] * w[10 * k + 5] * w[10 * k + 6] for k in range(a[1])), weight))
                 continue
             if kind == "pair":           # two products in one launch: their FLOPs add
                 calls.append((fn, a, 2.0 * a[6] * a[7] * a[8] + 2.0 * a[17] * a[18] * a[19], weight))
@@ -400,8 +404,9 @@ def main():
     peak = {"f32": PEAK_F32_MFMA_TFLOPS, "bf16": 2500.0, "bf16x3": 2500.0 / 3}[args.operands]
     dtype = {"f32": "f32", "bf16": "bf16 operands, f32 accumulate (data f32 in HBM)",
              "bf16x3": "f32 via split-bf16 (3 bf16 MFMAs per product), f32 accumulate"}[args.operands]
-    core = ("fp32 MFMA core: gemm_wk_kernel (small-batch products, K split inside the workgroup, fused consumers) + gemm_f32_kernel / "
-            "gemm_f32_pair_kernel (weight gradients, implicit-GEMM conv) + conv8_c32_kernel" if args.operands == "f32"
+    core = ("fp32 MFMA core: gemm_wk_kernel (small-batch products, K split inside the workgroup, fused consumers) + "
+            "gemm_f32_rms_multi_kernel / gemm_f32_kernel (weight gradients with RMSprop in the store, one launch per network) + "
+            "conv8_c32_kernel" if args.operands == "f32"
             else "bf16 MFMA core over fp32 data: gemm_mx_kernel (all layouts, implicit-GEMM conv)")
     # the same step with the contractions on the bf16 matrix pipe (gemm_mx.hip): reported beside the headline, never as
     # `value` (the headline stays the f32-operand parity path unless --operands says otherwise)

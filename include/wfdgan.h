@@ -185,6 +185,13 @@ int wfd_rmsprop_ranges(float* p, const float* g, float* sq, const long* ranges, 
 int wfd_gemm_f32_rmsprop(int layout, const float* A, int lda, const float* B, int ldb, int M, int N, int K, float* P,
                          int ldp, float* SQ, float lr, float alpha, float eps, void* stream);
 
+/* Up to 4 such weight matrices in ONE launch (the critic's three layers at the end of optimizer_D's step, the generator's
+ * four at the end of optimizer_G's, src/mlp_df_wgan_train.py:229-230, 273-275): desc (HOST memory) holds, per matrix, 10
+ * 64-bit words [A, lda, B, ldb, M, N, K, P, ldp, SQ] of a TN product as in wfd_gemm_f32_rmsprop(layout = 2).  The
+ * products must be independent of each other (none reads a P of the list).  Returns 1 when a problem does not fit the
+ * fast form (operands not 16-byte aligned, N <= 32, operand mode != f32): launch them one by one then.  Same bits. */
+int wfd_gemm_f32_rmsprop_multi(const long long* desc, int n, float lr, float alpha, float eps, void* stream);
+
 /* nn.BatchNorm1d(n, eps=0.8) training forward (src/model.py:23), in two halves so that data-parallel ranks can
  * combine (mean, M2) in between: stats writes Z = sumP + bias and the per-column mean / sum of squared deviations;
  * apply writes xhat, relu(gamma*xhat+beta), invstd and updates running_mean / running_var (unbiased) nupd times.

@@ -19,7 +19,10 @@ eng, _ = bench.build_engine(args, 0, 1, torch.device("cuda:0"))
 roof = bench.gemm_roofline(eng, rep=4, rounds=2)
 tot = sum(us * w for _, _, us, w, _ in roof["per_call"])
 for kind, fl, us, w, arg in roof["per_call"]:
-    if kind == "pair":
+    if kind == "rms_multi":
+        w = arg[0]
+        shape = "TN+rmsprop x%d: " % arg[1] + " | ".join(f"{w[10*k+4]}x{w[10*k+5]}x{w[10*k+6]}" for k in range(arg[1]))
+    elif kind == "pair":
         shape = f"TN {arg[6]}x{arg[7]}x{arg[8]} | lay{arg[9]} {arg[17]}x{arg[18]}x{arg[19]} ns={arg[20]}"
     elif kind == "gemm":
         shape = f"lay{arg[0]} M={arg[8]} N={arg[9]} K={arg[10]} ns={arg[11]}"

@@ -386,6 +386,20 @@ __global__ __launch_bounds__(NTHREADS) void gemm_f32_pair_kernel(GemmArgs g1, Ge
     }
 }
 
+// Several weight gradients with RMSprop in their stores as ONE launch (the three critic layers at the end of a D-step, the
+// four generator layers at the end of a G-step): the products are independent of each other, so their fill / drain phases
+// overlap each other's k-loops and the step pays one launch instead of three or four.  Blocks are dealt to the problems in
+// order (largest first); every problem is a TN product with 16-byte aligned operands and more than 32 columns.
+constexpr int MULTI_MAX = 4;
+struct MultiArgs { GemmArgs g[MULTI_MAX]; int nb[MULTI_MAX]; int gx[MULTI_MAX]; int n; };
+
+__global__ __launch_bounds__(NTHREADS) void gemm_f32_rms_multi_kernel(MultiArgs a) {
+    __shared__ __attribute__((aligned(16))) float lds[4 * TILE_F];
+    int id = blockIdx.x, k = 0;
+    while (k < a.n - 1 && id >= a.nb[k]) { id -= a.nb[k]; ++k; }       // uniform over the workgroup
+    gemm_f32_body<false, false, 4, 4, false, false, 2>(a.g[k], lds, id % a.gx[k], id / a.gx[k], 0);
+}
+
 template <bool AKC, bool BKC, bool IM2COL, bool NARROW, int EPI>
 int launch_gemm2(const GemmArgs& g, int splits, bool va4, bool vb4, hipStream_t st) {
     dim3 grid(NARROW ? cdiv(g.N, 32) : cdiv(g.N, BN), cdiv(g.M, BM), splits), block(NTHREADS);
@@ -861,6 +875,36 @@ int wfd_gemm_f32_rmsprop(int layout, const float* A, int lda, const float* B, in
         case 2: if (lda < M || ldb < N) return WFD_ERR_ARG; return launch_gemm<false, false, false>(g, 1, va4, vb4, st);
         default: return WFD_ERR_ARG;
     }
+}
+
+// desc (HOST memory): n problems x 10 64-bit words [A, lda, B, ldb, M, N, K, P, ldp, SQ], each as wfd_gemm_f32_rmsprop with
+// layout 2 (TN).  WFD_ERR_ARG when a problem does not fit the fast form (unaligned operands, N <= 32, n > 4): the caller
+// then launches them one by one.
+int wfd_gemm_f32_rmsprop_multi(const long long* desc, int n, float lr, float alpha, float eps, void* stream) {
+    if (!desc || n < 1 || n > MULTI_MAX || g_gemm_mode != 0) return WFD_ERR_ARG;
+    MultiArgs a{};
+    a.n = n;
+    long total = 0;
+    for (int k = 0; k < n; ++k) {
+        const long long* d = desc + 10 * k;
+        const float* A = reinterpret_cast<const float*>(d[0]);
+        const float* B = reinterpret_cast<const float*>(d[2]);
+        float* P = reinterpret_cast<float*>(d[7]);
+        float* SQ = reinterpret_cast<float*>(d[9]);
+        const int lda = (int)d[1], ldb = (int)d[3], M = (int)d[4], N = (int)d[5], K = (int)d[6], ldp = (int)d[8];
+        if (!A || !B || !P || !SQ || M <= 0 || N <= 32 || K <= 0 || ldp < N || lda < M || ldb < N) return WFD_ERR_ARG;
+        if (!aligned16(A) || !aligned16(B) || (lda & 3) || (ldb & 3) || !operands_fit(2, M, N, K, lda, ldb)) return WFD_ERR_ARG;
+        GemmArgs& g = a.g[k];
+        g.A = A; g.B = B; g.P = P; g.M = M; g.N = N; g.K = K; g.lda = lda; g.ldb = ldb; g.ldp = ldp;
+        g.ktiles_per_split = cdiv(K, BK);
+        g.epi = 4; g.sq = SQ; g.lr = lr; g.alpha = alpha; g.eps = eps;
+        a.gx[k] = cdiv(N, BN);
+        a.nb[k] = a.gx[k] * cdiv(M, BM);
+        total += a.nb[k];
+    }
+    hipLaunchKernelGGL(gemm_f32_rms_multi_kernel, dim3((unsigned)total), dim3(NTHREADS), 0, (hipStream_t)stream, a);
+    WFD_CHECK_LAUNCH();
+    return WFD_OK;
 }
 
 int wfd_conv8_gemm_f32_fused(const float* X, int Bn, int L, int Cin, int pad, const float* Wp, int Cout, float* out,

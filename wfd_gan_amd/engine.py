@@ -515,15 +515,16 @@ class TrainEngine:
         # operands exist
         Dp = D.p
         if self.fuse_d:
-            # single GPU: each t-chain product first (it reads W_i), then W_i's gradient with RMSprop in its store
-            lr = self.lr
+            # single GPU: the whole t-chain first (it reads W_1..W_3), then the three weight gradients, each consumed by RMSprop
+            # in its own store, as ONE launch
             ld1 = D.ld["model.0.weight"]
             p.gemm_mul(NT, b["XC"], self.ldx, Dp["model.0.weight"], ld1, M, 2048, S, b["D1"], 2048, DM_MUL, None, b["T1H1"][:M], 2048)
-            p.gemm_rms(TN, b["DL1"], 2048, b["XC"], self.ldx, 2048, S + C, 2 * M, Dp["model.0.weight"], ld1, D.s["model.0.weight"], lr)
             p.gemm_mul(NT, b["T1H1"][:M], 2048, Dp["model.3.weight"], 2048, M, 1024, 2048, b["D2"], 1024, DM_MUL, None, b["T2H2"][:M], 1024)
-            p.gemm_rms(TN, b["DL2"], 1024, b["T1H1"], 2048, 1024, 2048, 2 * M, Dp["model.3.weight"], 2048, D.s["model.3.weight"], lr)
             p.gemm_mul(NT, b["T2H2"][:M], 1024, Dp["model.6.weight"], 1024, M, 512, 1024, b["D3"], 512, DM_MUL, None, b["T3"], 512)
-            p.gemm_rms(TN, b["DL3"], 512, b["T2H2"], 1024, 512, 1024, 2 * M, Dp["model.6.weight"], 1024, D.s["model.6.weight"], lr)
+            p.gemm_rms_multi([
+                (b["DL1"], 2048, b["XC"], self.ldx, 2048, S + C, 2 * M, Dp["model.0.weight"], ld1, D.s["model.0.weight"]),
+                (b["DL2"], 1024, b["T1H1"], 2048, 1024, 2048, 2 * M, Dp["model.3.weight"], 2048, D.s["model.3.weight"]),
+                (b["DL3"], 512, b["T2H2"], 1024, 512, 1024, 2 * M, Dp["model.6.weight"], 1024, D.s["model.6.weight"])], self.lr)
         elif self.pair:
             # each layer's weight gradient (one TN product over the stacked [penalty ; standard] rows) shares a launch
             # with the t-chain product that follows it: neither reads what the other writes
@@ -749,18 +750,19 @@ class TrainEngine:
         if self.fuse_g:
             # single GPU: the activation gradient into layer k - 1 first (it reads W_k), then W_k's gradient with RMSprop in
             # its store
-            lr = self.lr
             s = p.gemm(NN, b["GDZ4"], self.lds4, Gp["model.8.weight"], 2048, B, 2048, S)
-            p.gemm_rms(TN, b["GDZ4"], self.lds4, b["GH3"], 2048, S, 2048, B, Gp["model.8.weight"], 2048, G.s["model.8.weight"], lr)
             self._bn_bwd(p, s, 3, "model.5", "model.6", 2048)
             s = p.gemm(NN, b["GDZ3"], 2048, Gp["model.5.weight"], 1024, B, 1024, 2048)
-            p.gemm_rms(TN, b["GDZ3"], 2048, b["GH2"], 1024, 2048, 1024, B, Gp["model.5.weight"], 1024, G.s["model.5.weight"], lr)
             self._bn_bwd(p, s, 2, "model.2", "model.3", 1024)
             p.gemm_mul(NN, b["GDZ2"], 1024, Gp["model.2.weight"], 512, B, 512, 1024, b["GH1"], 512, DM_RELU, None, b["GDZ1"], 512)
-            p.gemm_rms(TN, b["GDZ2"], 1024, b["GH1"], 512, 1024, 512, B, Gp["model.2.weight"], 512, G.s["model.2.weight"], lr)
             p.add(self.L.colsum, ptr(b["GDZ1"]), 512, B, 512, 0, ptr(G.g["model.0.bias"]), 0)
-            p.gemm_rms(TN, b["GDZ1"], 512, b["ZIN"], self.ldz, 512, Z + C, B, Gp["model.0.weight"], G.ld["model.0.weight"],
-                       G.s["model.0.weight"], lr)
+            # the activation-gradient chain is done (it read W_8, W_5, W_2): all four weight gradients, one launch
+            p.gemm_rms_multi([
+                (b["GDZ4"], self.lds4, b["GH3"], 2048, S, 2048, B, Gp["model.8.weight"], 2048, G.s["model.8.weight"]),
+                (b["GDZ3"], 2048, b["GH2"], 1024, 2048, 1024, B, Gp["model.5.weight"], 1024, G.s["model.5.weight"]),
+                (b["GDZ2"], 1024, b["GH1"], 512, 1024, 512, B, Gp["model.2.weight"], 512, G.s["model.2.weight"]),
+                (b["GDZ1"], 512, b["ZIN"], self.ldz, 512, Z + C, B, Gp["model.0.weight"], G.ld["model.0.weight"],
+                 G.s["model.0.weight"])], self.lr)
             self._optimizer(p, G, True, st if fast else 0, self._rng_inc() if fast else 0, 0)
             return p
         s = p.gemm_pair((b["GDZ4"], self.lds4, b["GH3"], 2048, S, 2048, B, G.g["model.8.weight"], 2048),

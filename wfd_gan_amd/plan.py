@@ -6,6 +6,7 @@ that only appends the stream, so the same plan can be run eagerly or captured in
 """
 from __future__ import annotations
 
+import os
 from collections import namedtuple
 from typing import List, Optional, Tuple
 
@@ -245,6 +246,26 @@ class Plan:
         """A weight gradient consumed in its own store: RMSprop on the parameter matrix ``P`` / square average ``SQ``
         (wfd_gemm_f32_rmsprop); the gradient is never written.  Unsplit contraction only."""
         self.add(self.L.gemm_f32_rmsprop, layout, ptr(A), lda, ptr(B), ldb, M, N, K, ptr(P), ldp, ptr(SQ), lr, alpha, eps)
+
+    def gemm_rms_multi(self, problems, lr: float, alpha: float = 0.99, eps: float = 1e-8):
+        """Several independent weight gradients consumed in their stores as ONE launch (wfd_gemm_f32_rmsprop_multi);
+        problems: [(A, lda, B, ldb, M, N, K, P, ldp, SQ)] of TN products, at most 4 per launch.  Falls back to one launch
+        each where the fast form does not apply (bf16-pipe modes, narrow or unaligned matrices)."""
+        import ctypes
+        ok = self.gemm_mode == 0 and all(N > 32 and ptr(A) % 16 == 0 and ptr(B) % 16 == 0 and lda % 4 == 0 and ldb % 4 == 0
+                                         for A, lda, B, ldb, M, N, K, P, ldp, SQ in problems)
+        if not ok or len(problems) < 2 or os.environ.get("WFD_RMS_MULTI", "1") == "0":      # (the switch: same-session A/B)
+            for A, lda, B, ldb, M, N, K, P, ldp, SQ in problems:
+                self.gemm_rms(TN, A, lda, B, ldb, M, N, K, P, ldp, SQ, lr, alpha, eps)
+            return
+        for a in range(0, len(problems), 4):
+            chunk = problems[a:a + 4]
+            words = []
+            for A, lda, B, ldb, M, N, K, P, ldp, SQ in chunk:
+                words += [ptr(A), lda, ptr(B), ldb, M, N, K, ptr(P), ldp, ptr(SQ)]
+            arr = (ctypes.c_longlong * len(words))(*words)
+            self.keep.append(arr)
+            self.add(self.L.gemm_f32_rmsprop_multi, arr, len(chunk), lr, alpha, eps)
 
     def gemm_pair(self, tn, other, pair: bool = True) -> Slabs:
         """A weight gradient and the next product of the backward chain, which do not depend on each other, as ONE launch
