@@ -88,6 +88,13 @@ int wfd_conv8_gemm_f32_fused(const float* X, int Bn, int L, int Cin, int pad, co
 int wfd_gemm_f32_wk(int layout, const float* A, int lda, const float* B, int ldb, int M, int N, int K, int epi, float* out,
                     int ldo, float* out2, int ldo2, const float* scale, const float* shift, int act, const float* D, int ldd,
                     int dmode, const float* rowscale, const float* mask, int ldmask, float slope, int cfg, void* stream);
+
+/* Up to 3 INDEPENDENT such products of one layout and configuration (3 or 4) in one launch: in the G-step
+ * (src/mlp_df_wgan_train.py:246-263) the critic's layer k on the generated rows and the DF observer's FC layer k read
+ * nothing of each other, and neither do the two input-gradient chains (:273).  desc (HOST memory): per product 24 64-bit
+ * words = the arguments of wfd_gemm_f32_wk in order (slope as the float's bit pattern).  Same bits as separate launches.
+ * Returns 1 when the products do not share layout / configuration: launch them one by one then. */
+int wfd_gemm_f32_wk_multi(const long long* desc, int n, void* stream);
 /* the k=8 "SAME" conv of wfd_conv8_gemm_f32 (src/model.py:92-105) in that form; Cin a multiple of 32; epi 0..2 */
 int wfd_conv8_f32_wk(const float* X, int Bn, int L, int Cin, int pad, const float* Wp, int Cout, int epi, float* out, int ldo,
                      const float* scale, const float* shift, int act, const float* D, int ldd, int dmode, int cfg,

@@ -164,6 +164,15 @@ def test_wk_bf16_pipe_modes(shape, layout, cfg, mode):
     assert (out[:, :N].double().cpu() - ref).abs().max().item() < tol
     if ldo > N:
         assert torch.isnan(out[:, N:]).all()
+    # ... and the bf16 pipe really ran: the same launch in f32 mode gives other bits (f32-input MFMA is ~1e-7 from fp64,
+    # the converted operands are not)
+    f32 = torch.full((M, ldo), float("nan"), device=DEV)
+    L.gemm_f32_wk(layout, A.data_ptr(), lda, B.data_ptr(), ldb, M, N, K, 0, f32.data_ptr(), ldo, 0, 0, 0, 0, 0, 0, 0, 0, 0,
+                  0, 0, 0.0, cfg, st)
+    torch.cuda.synchronize()
+    e_mode = (out[:, :N].double().cpu() - ref).abs().max().item()
+    e_f32 = (f32[:, :N].double().cpu() - ref).abs().max().item()
+    assert not torch.equal(out[:, :N], f32[:, :N]) and e_mode > 3 * e_f32, (e_mode, e_f32)
     z = ref + shift.double()
     assert (o1[:, :N].double().cpu() - F.leaky_relu(z, 0.2) * mask.double()).abs().max().item() < 1.25 * tol
     sure = z.abs() > 2 * tol

@@ -19,11 +19,20 @@
 // global loads disabled and 7.4 us with only the MFMAs disabled -- the loop runs at the f32 matrix pipe's rate
 // (188 x 16 MFMA steps of 32 cycles per SIMD = 5.9 us at 2.1 GHz); deeper prefetch (a second register set) bought
 // nothing and made hipcc spill the set to scratch.
+// TERMS (the operand mode of wfd_set_gemm_mode): 0 = f32-input MFMA as above; 1 / 2 = the bf16 matrix pipe over the same fp32
+// data (gemm_mx.hip's arithmetic): the fragments come out of LDS as fp32 exactly as before and are converted in registers --
+// x -> hi = bf16(x) [, lo = bf16(x - hi)] -- the four consecutive k a lane holds being precisely the lane's share of one
+// v_mfma_f32_16x16x16_bf16 (k = 4 * (lane >> 4) + 0..3), so one bf16 MFMA (TERMS = 1) or three (lo*hi + hi*lo + hi*hi,
+// TERMS = 2, products ~1e-5 relative) replace four f32 ones and nothing else in the kernel changes.
 // Layouts: NT (A[m][k], B[n][k]) and NN (A[m][k], B[k][n]); NT + IM2COL: A = channels-last activation of a k=8 "SAME" conv.
 // Operands must be 16-byte aligned with leading dimensions that are multiples of 4 floats (every buffer of the step is).
 #include "gemm_args.h"
 
 typedef float f32x4_ __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x4_ __attribute__((ext_vector_type(4)));
+typedef short s16x4_ __attribute__((ext_vector_type(4)));
+
+extern "C" int wfd_get_gemm_mode(void);
 
 namespace {
 
@@ -60,11 +69,9 @@ __device__ __forceinline__ void wave_lds_fence() {
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
-template <bool BKC, bool IM2COL, int RT, int CT, int NW>
-__global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(1, 2))) void gemm_wk_kernel(WkArgs g) {
-    // at most two waves per SIMD are ever resident (LDS: 9-18 KB per wave), so the register allocator may use 256 VGPRs:
-    // without the attribute it aims at four waves and spills the prefetched chunk to scratch
-    extern __shared__ __attribute__((aligned(16))) float smem[];
+// bid: the workgroup's index within ITS product (a launch may carry several products: gemm_wk_multi_kernel)
+template <bool BKC, bool IM2COL, int RT, int CT, int NW, int TERMS>
+__device__ __forceinline__ void gemm_wk_body(const WkArgs& g, float* __restrict__ smem, const int bid) {
     constexpr int TM = 16 * RT, TN = 16 * CT;
     constexpr int NA = TM / 8;                       // float4 loads per lane for an A chunk (8 lanes cover a 128-byte row segment)
     constexpr int NB = TN / 8;                       // ... for a B chunk (either layout: 32 x TN floats)
@@ -85,7 +92,7 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(1, 2)))
     // XCD-aware tile order: workgroup ids go round-robin over the 8 XCDs, so XCD x takes tiles [x*T8, (x+1)*T8) and the
     // row tiles that stream the same weight rows (consecutive v) share one L2
     const int T = g.mt * g.nt, T8 = (T + 7) >> 3;
-    const int v = (blockIdx.x & 7) * T8 + (blockIdx.x >> 3);
+    const int v = (bid & 7) * T8 + (bid >> 3);
     if (v >= T) return;                              // uniform over the workgroup, before any barrier
     const int m0 = (v % g.mt) * TM, n0 = (v / g.mt) * TN;
 
@@ -208,13 +215,41 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(1, 2)))
                     bf[b] = (f32x4_){p[0], p[LDB], p[2 * LDB], p[3 * LDB]};
                 }
             }
+            if constexpr (TERMS == 0) {
 #pragma unroll
-            for (int s = 0; s < 4; ++s)
+                for (int s = 0; s < 4; ++s)
+#pragma unroll
+                    for (int a = 0; a < RT; ++a)
+#pragma unroll
+                        for (int b = 0; b < CT; ++b)
+                            acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[a][s], bf[b][s], acc[a][b], 0, 0, 0);
+            } else {
+                s16x4_ ah[RT], al[RT], bh[CT], bl[CT];
+#pragma unroll
+                for (int a = 0; a < RT; ++a) {
+                    const bf16x4_ h = __builtin_convertvector(af[a], bf16x4_);
+                    ah[a] = __builtin_bit_cast(s16x4_, h);
+                    if constexpr (TERMS == 2)
+                        al[a] = __builtin_bit_cast(s16x4_, __builtin_convertvector(af[a] - __builtin_convertvector(h, f32x4_), bf16x4_));
+                }
+#pragma unroll
+                for (int b = 0; b < CT; ++b) {
+                    const bf16x4_ h = __builtin_convertvector(bf[b], bf16x4_);
+                    bh[b] = __builtin_bit_cast(s16x4_, h);
+                    if constexpr (TERMS == 2)
+                        bl[b] = __builtin_bit_cast(s16x4_, __builtin_convertvector(bf[b] - __builtin_convertvector(h, f32x4_), bf16x4_));
+                }
 #pragma unroll
                 for (int a = 0; a < RT; ++a)
 #pragma unroll
-                    for (int b = 0; b < CT; ++b)
-                        acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[a][s], bf[b][s], acc[a][b], 0, 0, 0);
+                    for (int b = 0; b < CT; ++b) {
+                        if constexpr (TERMS == 2) {
+                            acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(al[a], bh[b], acc[a][b], 0, 0, 0);
+                            acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(ah[a], bl[b], acc[a][b], 0, 0, 0);
+                        }
+                        acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(ah[a], bh[b], acc[a][b], 0, 0, 0);
+                    }
+            }
         }
     };
 
@@ -320,7 +355,63 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(1, 2)))
     }
 }
 
-template <bool BKC, bool IM2COL, int RT, int CT, int NW>
+template <bool BKC, bool IM2COL, int RT, int CT, int NW, int TERMS>
+__global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(1, 2))) void gemm_wk_kernel(WkArgs g) {
+    // at most two waves per SIMD are ever resident (LDS: 9-18 KB per wave), so the register allocator may use 256 VGPRs:
+    // without the attribute it aims at four waves and spills the prefetched chunk to scratch
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    gemm_wk_body<BKC, IM2COL, RT, CT, NW, TERMS>(g, smem, blockIdx.x);
+}
+
+// Several INDEPENDENT products of one layout and configuration in one launch (the observer's FC layer beside the critic's
+// layer of the same depth in the G-step): each product's workgroups keep their own XCD-aware order (every product takes a
+// multiple of 8 workgroups), the products' fill and drain phases overlap, and the step pays one launch for both.
+constexpr int WK_MULTI_MAX = 3;
+struct WkMulti { WkArgs g[WK_MULTI_MAX]; int nb[WK_MULTI_MAX]; int n; };
+
+template <bool BKC, int RT, int CT, int NW, int TERMS>
+__global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(1, 2))) void gemm_wk_multi_kernel(WkMulti a) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    int id = blockIdx.x, k = 0;
+    while (k < a.n - 1 && id >= a.nb[k]) { id -= a.nb[k]; ++k; }       // uniform over the workgroup
+    gemm_wk_body<BKC, false, RT, CT, NW, TERMS>(a.g[k], smem, id);
+}
+
+template <bool BKC, int RT, int CT, int NW, int TERMS>
+int launch_wk_multi(WkMulti a, hipStream_t st) {
+    constexpr int TM = 16 * RT, TN = 16 * CT;
+    constexpr int LDB = BKC ? LDK : TN + 4;
+    constexpr int WAVE_F = 2 * (TM * LDK + (BKC ? TN * LDK : KC * LDB));
+    const size_t lds = (size_t)NW * WAVE_F * sizeof(float);
+    static bool attr = false;
+    if (!attr) {
+        (void)hipFuncSetAttribute((const void*)gemm_wk_multi_kernel<BKC, RT, CT, NW, TERMS>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        attr = true;
+    }
+    long total = 0;
+    for (int k = 0; k < a.n; ++k) {
+        WkArgs& g = a.g[k];
+        g.mt = cdiv(g.M, TM);
+        g.nt = cdiv(g.N, TN);
+        g.cpw = cdiv(cdiv(g.K, KC), NW);
+        a.nb[k] = 8 * cdiv((long)g.mt * g.nt, 8);
+        total += a.nb[k];
+    }
+    hipLaunchKernelGGL((gemm_wk_multi_kernel<BKC, RT, CT, NW, TERMS>), dim3((unsigned)total), dim3(NW * 64), lds, st, a);
+    WFD_CHECK_LAUNCH();
+    return WFD_OK;
+}
+
+template <bool BKC, int TERMS>
+int launch_wk_multi_cfg(const WkMulti& a, int cfg, hipStream_t st) {
+    switch (cfg) {          // the two configurations the batch-64 step's paired products use
+        case 3: return launch_wk_multi<BKC, 2, 1, 4, TERMS>(a, st);
+        case 4: return launch_wk_multi<BKC, 2, 1, 8, TERMS>(a, st);
+        default: return WFD_ERR_ARG;
+    }
+}
+
+template <bool BKC, bool IM2COL, int RT, int CT, int NW, int TERMS>
 int launch_wk(WkArgs g, hipStream_t st) {
     constexpr int TM = 16 * RT, TN = 16 * CT;
     constexpr int LDB = BKC ? LDK : TN + 4;
@@ -328,27 +419,37 @@ int launch_wk(WkArgs g, hipStream_t st) {
     const size_t lds = (size_t)NW * WAVE_F * sizeof(float);
     static bool attr = false;
     if (!attr) {
-        (void)hipFuncSetAttribute((const void*)gemm_wk_kernel<BKC, IM2COL, RT, CT, NW>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        (void)hipFuncSetAttribute((const void*)gemm_wk_kernel<BKC, IM2COL, RT, CT, NW, TERMS>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         attr = true;
     }
     g.mt = cdiv(g.M, TM);
     g.nt = cdiv(g.N, TN);
     g.cpw = cdiv(cdiv(g.K, KC), NW);
     const int T8 = cdiv((long)g.mt * g.nt, 8);
-    hipLaunchKernelGGL((gemm_wk_kernel<BKC, IM2COL, RT, CT, NW>), dim3(8 * T8), dim3(NW * 64), lds, st, g);
+    hipLaunchKernelGGL((gemm_wk_kernel<BKC, IM2COL, RT, CT, NW, TERMS>), dim3(8 * T8), dim3(NW * 64), lds, st, g);
     WFD_CHECK_LAUNCH();
     return WFD_OK;
 }
 
+template <bool BKC, bool IM2COL, int TERMS>
+int launch_wk_cfg2(const WkArgs& g, int cfg, hipStream_t st) {
+    switch (cfg) {
+        case 1: return launch_wk<BKC, IM2COL, 2, 2, 4, TERMS>(g, st);      // 32 x 32 tile, 4 waves
+        case 2: return launch_wk<BKC, IM2COL, 2, 2, 8, TERMS>(g, st);      // 32 x 32 tile, 8 waves
+        case 3: return launch_wk<BKC, IM2COL, 2, 1, 4, TERMS>(g, st);      // 32 x 16 tile, 4 waves
+        case 4: return launch_wk<BKC, IM2COL, 2, 1, 8, TERMS>(g, st);      // 32 x 16 tile, 8 waves
+        case 5: return launch_wk<BKC, IM2COL, 2, 2, 2, TERMS>(g, st);      // 32 x 32 tile, 2 waves (many tiles, short K)
+        default: return WFD_ERR_ARG;
+    }
+}
+
+// operand mode (wfd_set_gemm_mode) read when the launch is issued (or captured), as in gemm.hip
 template <bool BKC, bool IM2COL>
 int launch_wk_cfg(const WkArgs& g, int cfg, hipStream_t st) {
-    switch (cfg) {
-        case 1: return launch_wk<BKC, IM2COL, 2, 2, 4>(g, st);      // 32 x 32 tile, 4 waves
-        case 2: return launch_wk<BKC, IM2COL, 2, 2, 8>(g, st);      // 32 x 32 tile, 8 waves
-        case 3: return launch_wk<BKC, IM2COL, 2, 1, 4>(g, st);      // 32 x 16 tile, 4 waves
-        case 4: return launch_wk<BKC, IM2COL, 2, 1, 8>(g, st);      // 32 x 16 tile, 8 waves
-        case 5: return launch_wk<BKC, IM2COL, 2, 2, 2>(g, st);      // 32 x 32 tile, 2 waves (many tiles, short K)
-        default: return WFD_ERR_ARG;
+    switch (wfd_get_gemm_mode()) {
+        case 1: return launch_wk_cfg2<BKC, IM2COL, 1>(g, cfg, st);
+        case 2: return launch_wk_cfg2<BKC, IM2COL, 2>(g, cfg, st);
+        default: return launch_wk_cfg2<BKC, IM2COL, 0>(g, cfg, st);
     }
 }
 
@@ -398,6 +499,49 @@ int wfd_gemm_f32_wk(int layout, const float* A, int lda, const float* B, int ldb
     hipStream_t st = (hipStream_t)stream;
     if (layout == 0) return launch_wk_cfg<true, false>(g, cfg, st);
     return launch_wk_cfg<false, false>(g, cfg, st);
+}
+
+// desc (HOST memory): n <= 3 products x 24 64-bit words, the arguments of wfd_gemm_f32_wk in order
+// [layout, A, lda, B, ldb, M, N, K, epi, out, ldo, out2, ldo2, scale, shift, act, D, ldd, dmode, rowscale, mask, ldmask,
+//  slope (the float's bits), cfg].  All products must share layout and configuration (3 or 4); returns WFD_ERR_ARG otherwise
+// (the caller launches them one by one).
+int wfd_gemm_f32_wk_multi(const long long* desc, int n, void* stream) {
+    if (!desc || n < 1 || n > WK_MULTI_MAX) return WFD_ERR_ARG;
+    WkMulti a{};
+    a.n = n;
+    const int layout = (int)desc[0], cfg = (int)desc[23];
+    for (int k = 0; k < n; ++k) {
+        const long long* d = desc + 24 * k;
+        WkArgs& g = a.g[k];
+        g.A = reinterpret_cast<const float*>(d[1]); g.lda = (int)d[2];
+        g.B = reinterpret_cast<const float*>(d[3]); g.ldb = (int)d[4];
+        g.M = (int)d[5]; g.N = (int)d[6]; g.K = (int)d[7]; g.epi = (int)d[8];
+        g.out = reinterpret_cast<float*>(d[9]); g.ldo = (int)d[10];
+        g.out2 = reinterpret_cast<float*>(d[11]); g.ldo2 = (int)d[12];
+        g.scale = reinterpret_cast<const float*>(d[13]); g.shift = reinterpret_cast<const float*>(d[14]); g.act = (int)d[15];
+        g.D = reinterpret_cast<const float*>(d[16]); g.ldd = (int)d[17]; g.dmode = (int)d[18];
+        g.rowscale = reinterpret_cast<const float*>(d[19]); g.mask = reinterpret_cast<const float*>(d[20]); g.ldmask = (int)d[21];
+        const unsigned sb = (unsigned)d[22];
+        __builtin_memcpy(&g.slope, &sb, sizeof(float));
+        if ((int)d[0] != layout || (int)d[23] != cfg || (layout != 0 && layout != 1)) return WFD_ERR_ARG;
+        if (!g.A || !g.B || !g.out || g.M <= 0 || g.N <= 0 || g.K <= 0 || g.ldo < g.N || g.epi < 0 || g.epi > 3) return WFD_ERR_ARG;
+        if (!al16(g.A) || !al16(g.B) || (g.lda & 3) || (g.ldb & 3) || g.lda < g.K || g.ldb < (layout == 0 ? g.K : g.N)) return WFD_ERR_ARG;
+        if ((long)g.M * g.lda >= (1L << 31) || (long)(layout == 0 ? g.N : g.K) * g.ldb >= (1L << 31)) return WFD_ERR_ARG;
+        if (g.out2 && g.ldo2 < g.N) return WFD_ERR_ARG;
+        if (g.epi == 2 && ((g.dmode && !g.D) || (g.out2 && !g.rowscale))) return WFD_ERR_ARG;
+        if (g.epi == 3 && (!g.shift || !g.mask || !g.out2)) return WFD_ERR_ARG;
+        if (g.epi < 2 && g.out2) return WFD_ERR_ARG;
+    }
+    hipStream_t st = (hipStream_t)stream;
+    const int mode = wfd_get_gemm_mode();
+    if (layout == 0) {
+        if (mode == 1) return launch_wk_multi_cfg<true, 1>(a, cfg, st);
+        if (mode == 2) return launch_wk_multi_cfg<true, 2>(a, cfg, st);
+        return launch_wk_multi_cfg<true, 0>(a, cfg, st);
+    }
+    if (mode == 1) return launch_wk_multi_cfg<false, 1>(a, cfg, st);
+    if (mode == 2) return launch_wk_multi_cfg<false, 2>(a, cfg, st);
+    return launch_wk_multi_cfg<false, 0>(a, cfg, st);
 }
 
 // k=8 "SAME" conv over a channels-last activation (wfd_conv8_gemm_f32's contraction) in the same form; Cin % 32 == 0
