@@ -473,6 +473,9 @@ int wfd_gemm_wk_pick(int layout, int M, int N, int K) {
         return (t16 >= 32 && nchunk >= 16) ? 4 : 0;
     }
     if (M > 256) return 0;
+    // the critic's input gradient (NN, 128 x 1401 x 2048: 176 tiles, a long K and a consumer -- the penalty row kernel -- that
+    // sums slabs anyway): split-K slabs beat every configuration here in the step (tools/wk_tune.py: -0.9 % per group)
+    if (layout == 1 && M > 64 && t32 >= 128 && t32 < 192 && nchunk >= 48) return 0;
     if (t32 >= 192) return nchunk >= 32 ? 2 : 1;
     if (t16 >= 96) return nchunk >= 32 ? 4 : 3;
     return nchunk >= 8 ? 4 : 3;
