@@ -106,7 +106,7 @@ def gemm_roofline(eng, plans=None, rep=16, rounds=3):
     L = eng.L
     gemm_fns = {L.gemm_f32: "gemm", L.conv8_gemm_f32: "conv", L.gemm_f32_fused: "gemm_fused",
                 L.conv8_gemm_f32_fused: "conv", L.gemm_f32_pair: "pair", L.gemm_f32_wk: "gemm_wk", L.conv8_f32_wk: "conv",
-                L.gemm_f32_rmsprop: "gemm_rms", L.gemm_f32_rmsprop_multi: "rms_multi"}
+                L.gemm_f32_rmsprop: "gemm_rms", L.gemm_f32_rmsprop_multi: "rms_multi", L.gemm_f32_wk_multi: "wk_multi"}
     calls = []
     for plan, weight in (plans or ((eng.fast_d, eng.n_critic), (eng.fast_g, 1))):
         for fn, a, _lane in plan.calls:
@@ -118,6 +118,10 @@ def gemm_roofline(eng, plans=None, rep=16, rounds=3):
             if kind == "rms_multi":      # several weight gradients in one launch: their FLOPs add
                 w = a[0]
                 calls.append((fn, a, sum(2.0 * w[10 * k + 4] * w[10 * k + 5] * w[10 * k + 6] for k in range(a[1])), weight))
+                continue
+            if kind == "wk_multi":       # independent products of one configuration in one launch: their FLOPs add
+                w = a[0]
+                calls.append((fn, a, sum(2.0 * w[24 * k + 5] * w[24 * k + 6] * w[24 * k + 7] for k in range(a[1])), weight))
                 continue
             if kind == "pair":           # two products in one launch: their FLOPs add
                 calls.append((fn, a, 2.0 * a[6] * a[7] * a[8] + 2.0 * a[17] * a[18] * a[19], weight))

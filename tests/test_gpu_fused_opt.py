@@ -204,3 +204,41 @@ def test_grouped_observer_ahead_is_bit_identical(graphs):
                     grp.slot(2).buf["DDF"].clone()] + [v.clone() for v in eng.Gbuf.values()])
     for k, (a, b) in enumerate(zip(*out)):
         assert torch.equal(a, b), f"tensor {k} differs between the two schedules"
+
+
+@pytest.mark.parametrize("name", ["tiny", "cfg2"])
+def test_g_step_merged_launches_are_bit_identical(name, monkeypatch):
+    """The G-step with its independent products of equal depth sharing launches (critic layer k beside observer FC layer k,
+    the two input-gradient chains side by side: Plan.batch -> wfd_gemm_f32_wk_multi) against one launch each: same kernels
+    on the same operands, so every output must be bit-identical; at config 2 the six pairs really share launches."""
+    fx, meta = load_iter_fixture(name)
+    B = meta["batch"]
+    engs = []
+    for merge in ("1", "0"):
+        monkeypatch.setenv("WFD_G_MERGE", merge)
+        st = rebuild_state(meta, fx)
+        with torch.no_grad():
+            st.D["model.9.bias"] += 0.3                  # the critic likes some fakes: the observer term is live
+        engs.append(_engine(st, meta, fuse_opt=True))
+    merged, plain = engs
+    assert merged.g_merge and not plain.g_merge
+    L = merged.L
+    n_multi = sum(fn is L.gemm_f32_wk_multi for fn, _, _ in merged.plan_g.calls)
+    assert not any(fn is L.gemm_f32_wk_multi for fn, _, _ in plain.plan_g.calls)
+    if name == "cfg2":
+        from wfd_gan_amd.plan import FORK, JOIN
+        launches = lambda e: sum(fn is not FORK and fn is not JOIN for fn, _, _ in e.plan_g.calls)
+        assert n_multi == 6 and launches(merged) == launches(plain) - 6
+    p = "it0_"
+    mr, mf, mg = unpack_masks(fx, p + "mreal", B), unpack_masks(fx, p + "mfake", B), unpack_masks(fx, p + "mg", B)
+    traces, labels, z = iter_inputs(fx, meta, 0)
+    for e in engs:
+        e.set_batch(torch.from_numpy(traces), torch.from_numpy(labels), torch.from_numpy(z))
+        e.set_masks([torch.cat([a, b]) for a, b in zip(mr, mf)], mg)
+        e.d_step()
+        e.g_step()
+    torch.cuda.synchronize()
+    assert merged.g_stats()["n_sel"] > 0
+    for k in ("LOG", "DLOG", "DDF", "GDZ4", "gV", "gDL1", "gstats"):
+        assert torch.equal(merged.buf[k], plain.buf[k]), k
+    assert torch.equal(merged.Gp.flat, plain.Gp.flat) and torch.equal(merged.Gp.sq, plain.Gp.sq)

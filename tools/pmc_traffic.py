@@ -10,7 +10,7 @@ import csv, glob, json, re, sys
 from collections import defaultdict
 
 def short(name):
-    m = re.search(r"(gemm_f32_kernel<[^>]*>|gemm_wk_kernel<[^>]*>|gemm_f32_pair_kernel<[^>]*>|gemm_f32_rms_multi_kernel|conv8_c32_kernel<[^>]*>|[A-Za-z0-9_]+_kernel)", name)
+    m = re.search(r"(gemm_f32_kernel<[^>]*>|gemm_wk_kernel<[^>]*>|gemm_wk_multi_kernel<[^>]*>|gemm_f32_pair_kernel<[^>]*>|gemm_f32_rms_multi_kernel|conv8_c32_kernel<[^>]*>|[A-Za-z0-9_]+_kernel)", name)
     return m.group(1) if m else name[:60]
 
 def load(d, counter):

@@ -19,7 +19,10 @@ eng, _ = bench.build_engine(args, 0, 1, torch.device("cuda:0"))
 roof = bench.gemm_roofline(eng, rep=4, rounds=2)
 tot = sum(us * w for _, _, us, w, _ in roof["per_call"])
 for kind, fl, us, w, arg in roof["per_call"]:
-    if kind == "rms_multi":
+    if kind == "wk_multi":
+        w = arg[0]
+        shape = "wk x%d: " % arg[1] + " | ".join(f"lay{w[24*k]} {w[24*k+5]}x{w[24*k+6]}x{w[24*k+7]}" for k in range(arg[1]))
+    elif kind == "rms_multi":
         w = arg[0]
         shape = "TN+rmsprop x%d: " % arg[1] + " | ".join(f"{w[10*k+4]}x{w[10*k+5]}x{w[10*k+6]}" for k in range(arg[1]))
     elif kind == "pair":

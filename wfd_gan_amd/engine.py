@@ -13,6 +13,7 @@ Real and fake rows are stacked (2B rows) so every weight matrix is streamed once
 from __future__ import annotations
 
 import ctypes
+import os
 import math
 from typing import Dict, List, Optional, Sequence, Tuple
 
@@ -155,7 +156,8 @@ def observer_buffers(df: "ObserverDF", B: int, device) -> Dict[str, object]:
         F1=z(B, 512), F2=z(B, 512), LOG=z(B, ldc), ldc=ldc)
 
 
-def observer_forward(p: Plan, df: "ObserverDF", X, ldx: int, xoff: int, B: int, Y, PO, F1, F2, LOG, ldc: int):
+def observer_forward(p: Plan, df: "ObserverDF", X, ldx: int, xoff: int, B: int, Y, PO, F1, F2, LOG, ldc: int,
+                     convs_only: bool = False):
     """DF.forward in eval mode (src/model.py:198-206) on x[b][l] = X[b*ldx + xoff + l] -> logits LOG[B][ldc]."""
     L = p.L
     Ls, cv = df.Ls, df.convs
@@ -169,10 +171,19 @@ def observer_forward(p: Plan, df: "ObserverDF", X, ldx: int, xoff: int, B: int, 
         if c["pool"]:
             p.add(L.df_pool8_fwd, ptr(cur), B, Ls[lvl], c["cout"], ptr(PO[pi]))
             cur, lvl, pi = PO[pi], lvl + 1, pi + 1
-    kin = 256 * Ls[4]
-    p.gemm_affine(NT, PO[3], kin, df.fc1_w, kin, B, 512, kin, df.fc1_scale, df.fc1_shift, ACT_RELU, F1, 512)
-    p.gemm_affine(NT, F1, 512, df.fc2_w, 512, B, 512, 512, df.fc2_scale, df.fc2_shift, ACT_RELU, F2, 512)
-    p.gemm_affine(NT, F2, 512, df.fc_w, 512, B, df.C, 512, None, df.fc_b, ACT_NONE, LOG, ldc)
+    if convs_only:
+        return
+    for step in observer_fc_steps(p, df, B, PO, F1, F2, LOG, ldc):
+        step()
+
+
+def observer_fc_steps(p: Plan, df: "ObserverDF", B: int, PO, F1, F2, LOG, ldc: int):
+    """The three FC layers of DF.forward (src/model.py:186-196, 204-205) as separately issuable steps."""
+    kin = 256 * df.Ls[4]
+    return [
+        lambda: p.gemm_affine(NT, PO[3], kin, df.fc1_w, kin, B, 512, kin, df.fc1_scale, df.fc1_shift, ACT_RELU, F1, 512),
+        lambda: p.gemm_affine(NT, F1, 512, df.fc2_w, 512, B, 512, 512, df.fc2_scale, df.fc2_shift, ACT_RELU, F2, 512),
+        lambda: p.gemm_affine(NT, F2, 512, df.fc_w, 512, B, df.C, 512, None, df.fc_b, ACT_NONE, LOG, ldc)]
 
 
 class TrainEngine:
@@ -330,6 +341,9 @@ class TrainEngine:
         # fast mode, data parallel: all ranks hold the same permutation; rank r takes rows [r*B, (r+1)*B) of each
         # run of B*world indices and the cursor advances by the rows all ranks consumed
         self.g_tail_fused = not self.exact and B <= 256
+        # the G-step's independent products of equal depth (critic layer k | observer FC layer k, and their two backward
+        # chains) share launches; WFD_G_MERGE=0: one launch each (same-session A/B)
+        self.g_merge = self.g_tail_fused and not overlap and self.wk and os.environ.get("WFD_G_MERGE", "1") != "0"
         # (f32 operand mode only: the bf16-pipe core applies the update with the parameter loads inside its store, which costs
         # more than the flat pass saves -- measured 2743 vs 3076 it/s in bf16x3 mode)
         fuse = bool(self.fuse_opt) and not self.dp and not overlap and self.gemm_mode == 0
@@ -674,10 +688,64 @@ class TrainEngine:
             p.add(self.L.masked_ce, ptr(b["LOG"]), self.ldc, B, self.C, ptr(b["labels"]), ptr(b["gV"]),
                   b["ghead"].data_ptr() + 4, self.alpha, ptr(b["CE"]), ptr(b["DLOG"]), self.ldc)
             p.add(self.L.g_loss, ptr(b["CE"]), B, ptr(b["ghead"]), self.alpha, ptr(b["gstats"]), ptr(b["gacc"]))
-        # ---- input gradient
-        p.gemm_mul(NN, b["DLOG"], self.ldc, df.fc_w, 512, B, 512, self.C, b["F2"], 512, DM_RELU, df.fc2_scale, b["DF2"], 512)
-        p.gemm_mul(NN, b["DF2"], 512, df.fc2_w, 512, B, 512, 512, b["F1"], 512, DM_RELU, df.fc1_scale, b["DF1"], 512)
-        p.gemm_mul(NN, b["DF1"], 512, df.fc1_w, kin, B, kin, 512, None, 0, DM_NONE, None, DPO[3], kin)
+        self._observer_backward(p)
+
+    def _observer_backward_fc_steps(self, p: Plan):
+        """Input gradient through the observer's three FC layers (src/model.py:186-196), as separately issuable steps."""
+        B, b, df = self.B, self.buf, self.df
+        kin = 256 * df.Ls[4]
+        return [
+            lambda: p.gemm_mul(NN, b["DLOG"], self.ldc, df.fc_w, 512, B, 512, self.C, b["F2"], 512, DM_RELU, df.fc2_scale, b["DF2"], 512),
+            lambda: p.gemm_mul(NN, b["DF2"], 512, df.fc2_w, 512, B, 512, 512, b["F1"], 512, DM_RELU, df.fc1_scale, b["DF1"], 512),
+            lambda: p.gemm_mul(NN, b["DF1"], 512, df.fc1_w, kin, B, kin, 512, None, 0, DM_NONE, None, b["DPO"][3], kin)]
+
+    def _g_front_merged(self, p: Plan) -> Slabs:
+        """The G-step up to the generator's backward with the INDEPENDENT products of equal depth sharing launches
+        (Plan.batch -> wfd_gemm_f32_wk_multi): the critic's three layers on the generated rows beside the observer's three FC
+        layers, and the critic's input-gradient chain beside the observer's FC backward chain.  Same kernels on the same
+        operands as the separate launches (bit-identical); 6 launches fewer.  Returns the slabs of g = (delta_1 W_1)[:, :S]."""
+        B, S, C, b, df = self.B, self.S, self.C, self.buf, self.df
+        D, ld1 = self.Dp.p, self.Dp.ld["model.0.weight"]
+        observer_forward(p, df, self.fake_rows, self.ldx, 1, B, b["Y"], b["PO"], b["F1"], b["F2"], b["LOG"], self.ldc,
+                         convs_only=True)
+        fc = observer_fc_steps(p, df, B, b["PO"], b["F1"], b["F2"], b["LOG"], self.ldc)
+        with p.batch():
+            fc[0]()
+            p.gemm_lrelu_drop(NT, self.fake_rows, self.ldx, D["model.0.weight"], ld1, B, 2048, S + C, D["model.0.bias"],
+                              b["gMK1"], 2048, b["gH1"], 2048, b["gD1"], 2048)
+        with p.batch():
+            fc[1]()
+            p.gemm_lrelu_drop(NT, b["gH1"], 2048, D["model.3.weight"], 2048, B, 1024, 2048, D["model.3.bias"], b["gMK2"], 1024,
+                              b["gH2"], 1024, b["gD2"], 1024)
+        with p.batch():
+            fc[2]()
+            with p.side(stream=False):           # slabs that must outlive the observer's main-lane products: side workspace
+                s = p.gemm(NT, b["gH2"], 1024, D["model.6.weight"], 1024, B, 512, 1024)
+        p.add(self.L.d_head_lrelu, s.ptr, s.ns, s.ss, s.ldp, ptr(D["model.6.bias"]), ptr(b["gMK3"]), 512, 0.2, ptr(b["gH3"]), 512,
+              ptr(b["gD3"]), 512, ptr(D["model.9.weight"]), ptr(D["model.9.bias"]), B, 512, 0, ptr(b["gV"]), ptr(b["gDL3"]), 0, 512)
+        p.add(self.L.g_tail, ptr(b["LOG"]), self.ldc, B, self.C, ptr(b["labels"]), ptr(b["gV"]), 1.0 / self.Bg, self.alpha,
+              ptr(b["CE"]), ptr(b["DLOG"]), self.ldc, ptr(b["ghead"]), ptr(b["gstats"]), ptr(b["gacc"]))
+        bw = self._observer_backward_fc_steps(p)
+        with p.batch():
+            bw[0]()
+            p.gemm_mul(NN, b["gDL3"], 512, D["model.6.weight"], 1024, B, 1024, 512, b["gD2"], 1024, DM_MUL, None, b["gDL2"], 1024)
+        with p.batch():
+            bw[1]()
+            p.gemm_mul(NN, b["gDL2"], 1024, D["model.3.weight"], 2048, B, 2048, 1024, b["gD1"], 2048, DM_MUL, None, b["gDL1"], 2048)
+        with p.batch():
+            bw[2]()
+            with p.side(stream=False):
+                g = p.gemm(NN, b["gDL1"], 2048, D["model.0.weight"], ld1, B, S, 2048)
+        self._observer_backward(p, fc=False)
+        return g
+
+    def _observer_backward(self, p: Plan, fc: bool = True):
+        B, b, df = self.B, self.buf, self.df
+        Ls, Y, PO, DC, DPO = df.Ls, b["Y"], b["PO"], b["DC"], b["DPO"]
+        cv = df.convs
+        if fc:
+            for step in self._observer_backward_fc_steps(p):
+                step()
         # walk the conv stack backwards; `lvl` = index of the length the conv runs at
         k, lvl, pi = 6, 3, 3
         while k >= 1:
@@ -726,15 +794,19 @@ class TrainEngine:
               2 if bn_stacked is not None else 1)
         # side lane: critic pass on the fake rows + its input-gradient chain (slabs stay in the side workspace until
         # g_out_bwd reads them); main lane: the DF observer forward.  They meet at the masked CE.
-        if observer_forward:
-            p.fork()
-        with p.side(stream=observer_forward):       # the slabs of g stay in the side workspace either way
-            self._critic_forward(p, self.fake_rows, B, (b["gMK1"], b["gMK2"], b["gMK3"]), b["gH1"], b["gH2"],
-                                 b["gH3"], b["gD1"], b["gD2"], b["gD3"], b["gV"], b["gDL3"], None, None)
-            if not self.g_tail_fused:
-                p.add(self.L.g_head, ptr(b["gV"]), B, 1.0 / self.Bg, ptr(b["ghead"]))
-            g = self._critic_chain(p, B, b["gDL3"], b["gDL2"], None, b["gDL1"], None, b["gD2"], b["gD1"], None)
-        self._observer(p, forward=observer_forward)
+        merged = self.g_merge and observer_forward
+        if merged:
+            g = self._g_front_merged(p)
+        else:
+            if observer_forward:
+                p.fork()
+            with p.side(stream=observer_forward):       # the slabs of g stay in the side workspace either way
+                self._critic_forward(p, self.fake_rows, B, (b["gMK1"], b["gMK2"], b["gMK3"]), b["gH1"], b["gH2"],
+                                     b["gH3"], b["gD1"], b["gD2"], b["gD3"], b["gV"], b["gDL3"], None, None)
+                if not self.g_tail_fused:
+                    p.add(self.L.g_head, ptr(b["gV"]), B, 1.0 / self.Bg, ptr(b["ghead"]))
+                g = self._critic_chain(p, B, b["gDL3"], b["gDL2"], None, b["gDL1"], None, b["gD2"], b["gD1"], None)
+            self._observer(p, forward=observer_forward)
         if B > 512:      # tall batch: dz in one fully parallel pass, its column sums (the bias gradient) by row chunks
             part = b.setdefault("gout_part", torch.zeros(((B + 127) // 128) * S, dtype=torch.float32, device=self.dev))
             p.add(self.L.g_out_bwd, g.ptr, g.ns, g.ss, g.ldp, B, S, -1.0 / self.Bg, ptr(b["DDF"]), self.ldl,

@@ -67,6 +67,7 @@ class Plan:
         # device tensors that only this plan's launches reference by raw pointer (descriptor tables): they live as long as
         # the plan (and any plan it is concatenated into, and the graphs captured from it, which keep the plan alive)
         self.keep: List[torch.Tensor] = []
+        self._batch = None                             # wk products being collected for one launch (batch())
         self.lane = 0                                  # stream lane of the launches being added
         self.wsl = 0                                   # lane whose slab workspace they use
         self.overlap = self.two and overlap            # side lane on its own stream (else: same stream, in order)
@@ -201,8 +202,47 @@ class Plan:
 
     def _wk(self, layout, A, lda, B, ldb, M, N, K, cfg, epi, out, ldo, out2=None, ldo2=0, scale=None, shift=None, act=0,
             D=None, ldd=0, dmode=0, rowscale=None, mask=None, ldmask=0, slope=0.0):
-        self.add(self.L.gemm_f32_wk, layout, ptr(A), lda, ptr(B), ldb, M, N, K, epi, ptr(out), ldo, ptr(out2), ldo2,
-                 ptr(scale), ptr(shift), act, ptr(D), ldd, dmode, ptr(rowscale), ptr(mask), ldmask, slope, cfg)
+        args = (layout, ptr(A), lda, ptr(B), ldb, M, N, K, epi, ptr(out), ldo, ptr(out2), ldo2, ptr(scale), ptr(shift), act,
+                ptr(D), ldd, dmode, ptr(rowscale), ptr(mask), ldmask, slope, cfg)
+        if self._batch is not None:
+            self._batch.append(args)
+        else:
+            self.add(self.L.gemm_f32_wk, *args)
+
+    class _Batch:
+        def __init__(self, plan):
+            self.plan = plan
+
+        def __enter__(self):
+            self.plan._batch = []
+
+        def __exit__(self, *exc):
+            calls, self.plan._batch = self.plan._batch, None
+            self.plan._flush_batch(calls)
+
+    def batch(self):
+        """``with plan.batch(): ...``: the split-inside-the-workgroup products built inside are INDEPENDENT of each other (the
+        caller's promise) and go out as one launch (wfd_gemm_f32_wk_multi) when they share layout and configuration;
+        otherwise, and for everything else built inside, one launch each as usual."""
+        return Plan._Batch(self)
+
+    def _flush_batch(self, calls):
+        import ctypes
+        import struct
+        same = len({(c[0], c[23]) for c in calls}) == 1
+        if len(calls) < 2 or len(calls) > 3 or not same or calls[0][23] not in (3, 4) or \
+                os.environ.get("WFD_WK_MULTI", "1") == "0":      # (the switch: same-session A/B)
+            for c in calls:
+                self.add(self.L.gemm_f32_wk, *c)
+            return
+        words = []
+        for c in calls:
+            w = list(c)
+            w[22] = struct.unpack("<I", struct.pack("<f", float(c[22])))[0]      # slope: the float's bits
+            words += [int(v) for v in w]
+        arr = (ctypes.c_longlong * len(words))(*words)
+        self.keep.append(arr)
+        self.add(self.L.gemm_f32_wk_multi, arr, len(calls))
 
     def gemm(self, layout: int, A, lda: int, B, ldb: int, M: int, N: int, K: int, out=None, ldp: Optional[int] = None,
              splits: Optional[int] = None) -> Slabs:
