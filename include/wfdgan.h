@@ -274,8 +274,8 @@ int wfd_masked_ce(const float* logits, int ldl, int M, int C, const int* labels,
 /* out[4] = {g_loss, f_loss, g_loss + alpha f_loss, nsel}; acc[4] += {g_loss, f_loss, combined, 1} (:263-271) */
 int wfd_g_loss(const float* ce, int B, const float* head, float alpha, float* out, float* acc, void* stream);
 
-/* wfd_g_head + wfd_masked_ce + wfd_g_loss in ONE launch (one workgroup; B <= 256: the batches of the reference's
- * configuration), src/mlp_df_wgan_train.py:247-271: head[2] = {-mean(fv), #{fv > 0}}, ce / dlogits as wfd_masked_ce,
+/* wfd_g_head + wfd_masked_ce + wfd_g_loss in ONE launch (one workgroup; B <= 256 rows, C <= 128 classes: the
+ * reference's configurations), src/mlp_df_wgan_train.py:247-271: head[2] = {-mean(fv), #{fv > 0}}, ce / dlogits as wfd_masked_ce,
  * out[4] / acc[4] as wfd_g_loss.  Single rank only (the exact data-parallel mode all-reduces head in between). */
 int wfd_g_tail(const float* logits, int ldl, int B, int C, const int* labels, const float* fv, float invB, float alpha,
                float* ce, float* dlogits, int lddl, float* head, float* out, float* acc, void* stream);

@@ -317,3 +317,36 @@ def test_d_head_lrelu_equals_the_two_launches(shape):
     h = torch.where(z > 0, z, 0.2 * z) * mask[:, :K].double().cpu()
     ref = h @ w4.double().cpu() + b4.double().cpu()
     assert (outs[1][2].double().cpu() - ref).abs().max().item() <= 1e-4 * (1 + ref.abs().max().item())
+
+
+@pytest.mark.parametrize("B,C", [(8, 5), (64, 100), (200, 128), (33, 64), (64, 65)])
+def test_g_tail_equals_its_three_launches(B, C):
+    """wfd_g_tail (one workgroup) against wfd_g_head + wfd_masked_ce + wfd_g_loss on the same logits / labels / critic
+    scores (src/mlp_df_wgan_train.py:247-271), and against torch's cross_entropy on the selected rows."""
+    L, st = _L()
+    g = torch.Generator().manual_seed(B * 1000 + C)
+    ldl = (C + 3) // 4 * 4
+    logits = torch.randn(B, ldl, generator=g) * 3
+    labels = torch.randint(0, C, (B,), generator=g, dtype=torch.int32)
+    fv = torch.randn(B, generator=g)
+    ld, lb, fd = logits.to(DEV), labels.to(DEV), fv.to(DEV)
+    outs = []
+    for fused in (True, False):
+        ce, dl = torch.zeros(B, device=DEV), torch.zeros(B, ldl, device=DEV)
+        head, stats, acc = torch.zeros(2, device=DEV), torch.zeros(4, device=DEV), torch.ones(4, device=DEV)
+        if fused:
+            L.g_tail(ld.data_ptr(), ldl, B, C, lb.data_ptr(), fd.data_ptr(), 1.0 / B, 0.02, ce.data_ptr(), dl.data_ptr(), ldl,
+                     head.data_ptr(), stats.data_ptr(), acc.data_ptr(), st)
+        else:
+            L.g_head(fd.data_ptr(), B, 1.0 / B, head.data_ptr(), st)
+            L.masked_ce(ld.data_ptr(), ldl, B, C, lb.data_ptr(), fd.data_ptr(), head.data_ptr() + 4, 0.02, ce.data_ptr(),
+                        dl.data_ptr(), ldl, st)
+            L.g_loss(ce.data_ptr(), B, head.data_ptr(), 0.02, stats.data_ptr(), acc.data_ptr(), st)
+        torch.cuda.synchronize()
+        outs.append((ce.cpu(), dl.cpu()[:, :C], head.cpu(), stats.cpu(), acc.cpu()))
+    for a, b, what in zip(outs[0], outs[1], ("ce", "dlogits", "head", "stats", "acc")):
+        assert float((a - b).abs().max()) <= 2e-6 * max(1.0, float(b.abs().max())), what
+    sel = fv > 0
+    want = torch.nn.functional.cross_entropy(logits[sel][:, :C].double(), labels[sel].long()) if sel.any() else torch.tensor(0.0)
+    assert abs(float(outs[0][3][1]) - float(want)) <= 1e-5 * max(1.0, abs(float(want)))
+    assert float(outs[0][3][3]) == float(sel.sum())

@@ -154,6 +154,21 @@ __global__ __launch_bounds__(1024) void g_tail_kernel(const float* __restrict__ 
     __shared__ float red[16];
     __shared__ float hd[2];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
+    // every global load of the launch is issued up front (one latency, not one per dependent step): the wave's rows of logits
+    // (C <= 128: two per lane and row; up to 16 rows per wave at B = 256), their labels and critic scores
+    constexpr int RMAX = 16;
+    float x0[RMAX], x1[RMAX], fvr[RMAX];
+    int lab[RMAX];
+#pragma unroll
+    for (int j = 0; j < RMAX; ++j) {
+        const int m = wave + nw * j;
+        const bool ok = m < B;
+        const float* row = logits + (long)(ok ? m : 0) * ldl;
+        x0[j] = (ok && lane < C) ? row[lane] : -INFINITY;
+        x1[j] = (ok && lane + 64 < C) ? row[lane + 64] : -INFINITY;
+        lab[j] = ok ? labels[m] : 0;
+        fvr[j] = ok ? fv[m] : 0.f;
+    }
     float s = 0.f, c = 0.f;
     for (int i = threadIdx.x; i < B; i += blockDim.x) { s += fv[i]; c += fv[i] > 0.f ? 1.f : 0.f; }
     s = block_sum(s, red);
@@ -162,24 +177,22 @@ __global__ __launch_bounds__(1024) void g_tail_kernel(const float* __restrict__ 
     __syncthreads();
     const float nsel = hd[1];
     float cesum = 0.f;
-    for (int m = wave; m < B; m += nw) {
-        const float* row = logits + (long)m * ldl;
-        float mx = -INFINITY;
-        for (int k = lane; k < C; k += 64) mx = fmaxf(mx, row[k]);
-        mx = wave_max(mx);
-        float e = 0.f;
-        for (int k = lane; k < C; k += 64) e += expf(row[k] - mx);
-        e = wave_sum(e);
-        const float lse = mx + logf(e);
-        const int lab = labels[m];
-        const float sel = fv[m] > 0.f ? 1.f : 0.f;
+#pragma unroll
+    for (int j = 0; j < RMAX; ++j) {
+        const int m = wave + nw * j;
+        if (m >= B) break;                                  // uniform over the wave
+        const float mx = wave_max(fmaxf(x0[j], x1[j]));
+        const float e0 = lane < C ? expf(x0[j] - mx) : 0.f, e1 = lane + 64 < C ? expf(x1[j] - mx) : 0.f;
+        const float lse = mx + logf(wave_sum(e0 + e1));
+        const float sel = fvr[j] > 0.f ? 1.f : 0.f;
         const float w = nsel > 0.f ? alpha * sel / nsel : 0.f;
-        const float cem = sel * (lse - row[lab]);
+        // logit of the label: held by lane lab % 64 in x0 (lab < 64) or x1
+        const float mine = lab[j] < 64 ? x0[j] : x1[j];
+        const float xl = __shfl(mine, lab[j] & 63, 64);
+        const float cem = sel * (lse - xl);
         if (lane == 0) { ce[m] = cem; cesum += cem; }
-        for (int k = lane; k < C; k += 64) {
-            const float p = expf(row[k] - lse);
-            dlogits[(long)m * lddl + k] = w * (p - (k == lab ? 1.f : 0.f));
-        }
+        if (lane < C) dlogits[(long)m * lddl + lane] = w * (expf(x0[j] - lse) - (lane == lab[j] ? 1.f : 0.f));
+        if (lane + 64 < C) dlogits[(long)m * lddl + lane + 64] = w * (expf(x1[j] - lse) - (lane + 64 == lab[j] ? 1.f : 0.f));
     }
     cesum = block_sum(cesum, red);
     if (threadIdx.x == 0) {
@@ -273,7 +286,7 @@ int wfd_masked_ce(const float* logits, int ldl, int M, int C, const int* labels,
 
 int wfd_g_tail(const float* logits, int ldl, int B, int C, const int* labels, const float* fv, float invB, float alpha,
                float* ce, float* dlogits, int lddl, float* head, float* out, float* acc, void* stream) {
-    if (!logits || !labels || !fv || !ce || !dlogits || !head || !out || B < 1 || B > 256 || C < 1) return WFD_ERR_ARG;
+    if (!logits || !labels || !fv || !ce || !dlogits || !head || !out || B < 1 || B > 256 || C < 1 || C > 128) return WFD_ERR_ARG;
     hipLaunchKernelGGL(g_tail_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, logits, ldl, B, C, labels, fv, invB,
                        alpha, ce, dlogits, lddl, head, out, acc);
     WFD_CHECK_LAUNCH();

@@ -340,7 +340,7 @@ class TrainEngine:
         self.gf_state = share.gf_state if share is not None else torch.zeros(2, dtype=torch.int64, device=dev)
         # fast mode, data parallel: all ranks hold the same permutation; rank r takes rows [r*B, (r+1)*B) of each
         # run of B*world indices and the cursor advances by the rows all ranks consumed
-        self.g_tail_fused = not self.exact and B <= 256
+        self.g_tail_fused = not self.exact and B <= 256 and C <= 128
         # the G-step's independent products of equal depth (critic layer k | observer FC layer k, and their two backward
         # chains) share launches; WFD_G_MERGE=0: one launch each (same-session A/B)
         self.g_merge = self.g_tail_fused and not overlap and self.wk and os.environ.get("WFD_G_MERGE", "1") != "0"
