@@ -242,3 +242,36 @@ def test_g_step_merged_launches_are_bit_identical(name, monkeypatch):
     for k in ("LOG", "DLOG", "DDF", "GDZ4", "gV", "gDL1", "gstats"):
         assert torch.equal(merged.buf[k], plain.buf[k]), k
     assert torch.equal(merged.Gp.flat, plain.Gp.flat) and torch.equal(merged.Gp.sq, plain.Gp.sq)
+
+
+def test_gemm_rmsprop_multi_equals_separate_launches():
+    """wfd_gemm_f32_rmsprop_multi: the critic's three weight gradients (config-2 shapes) in one launch == three
+    wfd_gemm_f32_rmsprop launches, bit for bit, over two steps; a narrow matrix is rejected (the caller falls back)."""
+    L, st = _L()
+    g = torch.Generator().manual_seed(11)
+    shapes = [(2048, 1501, 256), (1024, 2048, 256), (512, 1024, 256)]
+    P, SQ, A, B = [], [], [], []
+    for M, N, K in shapes:
+        ldp = (N + 3) // 4 * 4
+        p0 = torch.randn(M, ldp, generator=g)
+        P.append([p0.to(DEV), p0.to(DEV)])
+        SQ.append([torch.zeros(M, ldp, device=DEV), torch.zeros(M, ldp, device=DEV)])
+    for step in range(2):
+        words = []
+        ops = []
+        for k, (M, N, K) in enumerate(shapes):
+            ldp = (N + 3) // 4 * 4
+            a, b = torch.randn(K, M, generator=g).to(DEV), torch.randn(K, ldp, generator=g).to(DEV)
+            ops += [a, b]
+            L.gemm_f32_rmsprop(2, a.data_ptr(), M, b.data_ptr(), ldp, M, N, K, P[k][0].data_ptr(), ldp, SQ[k][0].data_ptr(),
+                               2e-4, 0.99, 1e-8, st)
+            words += [a.data_ptr(), M, b.data_ptr(), ldp, M, N, K, P[k][1].data_ptr(), ldp, SQ[k][1].data_ptr()]
+        arr = (ctypes.c_longlong * len(words))(*words)
+        L.gemm_f32_rmsprop_multi(arr, 3, 2e-4, 0.99, 1e-8, st)
+        torch.cuda.synchronize()
+        for k in range(3):
+            assert torch.equal(P[k][0], P[k][1]) and torch.equal(SQ[k][0], SQ[k][1]), (step, k)
+    assert float((P[0][0] - P[0][0].clone().zero_()).abs().max()) > 0
+    words[5] = 24                                                # N <= 32: not the fast form
+    with pytest.raises(Exception):
+        L.gemm_f32_rmsprop_multi((ctypes.c_longlong * len(words))(*words), 3, 2e-4, 0.99, 1e-8, st)

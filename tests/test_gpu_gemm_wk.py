@@ -204,3 +204,47 @@ def test_wk_conv8_bf16_pipe_modes(geom, mode):
         L.set_gemm_mode(0)
     tol = {1: 2e-2, 2: 1e-4}[mode] * 1.5 * max(1.0, ref.abs().max().item())
     assert (out.double().cpu() - want).abs().max().item() < tol
+
+
+@pytest.mark.parametrize("layout,cfg", [(0, 4), (1, 4), (1, 3), (0, 3)])
+def test_wk_multi_equals_separate_launches(layout, cfg):
+    """wfd_gemm_f32_wk_multi: three independent products of one layout / configuration (different shapes and epilogues)
+    in one launch are bit-identical to their own launches; mismatched configurations are rejected."""
+    import ctypes
+    import struct
+    L, st = _L()
+    shapes = [(64, 512, 256), (64, 2048, 1501), (33, 100, 512)]
+    keep, calls = [], []
+    for k, (M, N, K) in enumerate(shapes):
+        A, lda, B, ldb, ref, g = _operands(layout, M, N, K, seed=50 + k)
+        ldo = rup(N)
+        shift = torch.randn(N, generator=g).to(DEV)
+        mask = ((torch.rand(M, N, generator=g) > 0.2).float() * 1.25).to(DEV)
+        epi = (1, 3, 0)[k]
+        outs = [[torch.full((M, ldo), float("nan"), device=DEV) for _ in range(2)] for _ in range(2)]
+        keep += [A, B, shift, mask, outs]
+        for o1, o2 in outs:
+            calls.append([layout, A.data_ptr(), lda, B.data_ptr(), ldb, M, N, K, epi, o1.data_ptr(), ldo,
+                          o2.data_ptr() if epi == 3 else 0, ldo if epi == 3 else 0, 0, shift.data_ptr() if epi else 0,
+                          1 if epi == 1 else 0, 0, 0, 0, 0, mask.data_ptr() if epi == 3 else 0, N if epi == 3 else 0, 0.2, cfg])
+    for c in calls[0::2]:                                       # separate launches into the first output set
+        L.gemm_f32_wk(*c, st)
+    words = []
+    for c in calls[1::2]:                                       # one launch into the second
+        w = list(c)
+        w[22] = struct.unpack("<I", struct.pack("<f", 0.2))[0]
+        words += [int(v) for v in w]
+    arr = (ctypes.c_longlong * len(words))(*words)
+    L.gemm_f32_wk_multi(arr, 3, st)
+    torch.cuda.synchronize()
+    for k in range(3):
+        (a1, a2), (b1, b2) = keep[5 * k + 4]
+        N = shapes[k][1]
+        assert torch.equal(a1[:, :N], b1[:, :N]), k
+        if (1, 3, 0)[k] == 3:
+            assert torch.equal(a2[:, :N], b2[:, :N]), k
+        assert not torch.isnan(b1[:, :N]).any()
+    words[23] = 2 if cfg != 2 else 1                             # first product claims another configuration
+    bad = (ctypes.c_longlong * len(words))(*words)
+    with pytest.raises(Exception):
+        L.gemm_f32_wk_multi(bad, 3, st)
