@@ -27,7 +27,7 @@ constexpr int BM = 64, BN = 64, BK = 32, NTHREADS = 256;
 // unused GemmArgs::D of a raw (EPI = false) launch.  The product library is built without WFD_STAMPS: no stamp executes.
 #ifdef WFD_STAMPS
 #define WFD_STAMP(slot)                                                                                         \
-    if (!EPI && g.D && threadIdx.x == 0) {                                                                       \
+    if ((EPI == 0 || EPI == 2) && g.D && threadIdx.x == 0) {                                                                       \
         const long wg_ = (long)bz * 65536 + (long)by * 256 + bx;                                                 \
         reinterpret_cast<unsigned long long*>(const_cast<float*>(g.D))[(wg_ % g.ldd) * 4 + slot] = __builtin_amdgcn_s_memrealtime(); \
     }
@@ -676,6 +676,14 @@ bool wfd_mx_conv_direct(int M, int Cin, int Cout, int terms);
 
 extern "C" {
 
+#ifdef WFD_STAMPS
+static unsigned long long* g_multi_stamps = nullptr;
+static int g_multi_nslots = 0;
+// diagnostic build: the next wfd_gemm_f32_rmsprop_multi launches write their stamps here (nslots x 4 u64 per problem;
+// tools/rms_multi_stamps.py)
+int wfd_rms_multi_set_stamps(unsigned long long* stamps, int nslots) { g_multi_stamps = stamps; g_multi_nslots = nslots; return 0; }
+#endif
+
 int wfd_set_gemm_mode(int mode) {
     if (mode < 0 || mode > 2) return WFD_ERR_ARG;
     g_gemm_mode = mode;
@@ -902,6 +910,11 @@ int wfd_gemm_f32_rmsprop_multi(const long long* desc, int n, float lr, float alp
         a.nb[k] = a.gx[k] * cdiv(M, BM);
         total += a.nb[k];
     }
+#ifdef WFD_STAMPS
+    if (g_multi_stamps) for (int k = 0; k < n; ++k) {
+        a.g[k].D = reinterpret_cast<const float*>(g_multi_stamps + (long)k * g_multi_nslots * 4); a.g[k].ldd = g_multi_nslots;
+    }
+#endif
     hipLaunchKernelGGL(gemm_f32_rms_multi_kernel, dim3((unsigned)total), dim3(NTHREADS), 0, (hipStream_t)stream, a);
     WFD_CHECK_LAUNCH();
     return WFD_OK;
