@@ -385,6 +385,22 @@ int wfd_ep_sigmoid_lenmask_slots(const float* P, int ns, long ss, int ldp, int M
                                  float smin, float* out, int ldo, int rows_per_slot, long slot_stride, int* idx, int* err,
                                  void* stream);
 
+/* wfd_ep_sigmoid_lenmask_slots that also advances the device iteration state (wfd_iter_advance folded into the launch:
+ * state[0] += inc0, state[1] += inc1; nothing in the launch reads the state) */
+int wfd_ep_sigmoid_lenmask_slots_adv(const float* P, int ns, long ss, int ldp, int M, int S, const float* bias, float range,
+                                     float smin, float* out, int ldo, int rows_per_slot, long slot_stride, int* idx, int* err,
+                                     unsigned long long* state, unsigned long long inc0, unsigned long long inc1,
+                                     void* stream);
+/* everything a group of n_critic iterations draws before its first product as ONE launch: wfd_rng_dropout_mask_slots
+ * (mslots, nslots, p, mask_state) + wfd_gather_batch_slots (X ... labels_out; the DataLoader + one-hot of
+ * src/mlp_df_wgan_train.py:184-186 for `slots` batches) + wfd_rng_normal_rows on the B * slots rows of zin, columns
+ * [0, Z), Philox key zseed at counter state[0] (the z of src/mlp_df_wgan_train.py:194).  Same values as the three. */
+int wfd_group_inputs(const unsigned long long* mslots, int nslots, float p, const unsigned long long* mask_state,
+                     const float* X, int ldX, const int* y, const long long* idx, const unsigned long long* state,
+                     long n_idx, long n_rows, long row_offset, int B, int slots, long slot_idx_stride, int S, int C,
+                     float* real, float* fake, int ldd, long slot_stride, float* zin, int ldz, int Z, int* labels_out,
+                     unsigned long long zseed, void* stream);
+
 /* ---- DF observer training (src/train_df.py:111-131 around src/model.py:135-206 in train mode) ---------------------- */
 
 /* weight gradient of the k=8 "SAME" conv (autograd of MyConv1dPadSame, src/model.py:91-104):

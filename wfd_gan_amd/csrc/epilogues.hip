@@ -734,8 +734,13 @@ __global__ __launch_bounds__(CTS * RG) void bn_bwd_small_kernel(
 __global__ void ep_sigmoid_lenmask_kernel(const float* __restrict__ P, int ns, long ss, int ldp, int S,
                                           const float* __restrict__ bias, float range, float smin,
                                           float* __restrict__ out, int ldo, int* __restrict__ idx_out,
-                                          int* __restrict__ err, int rows_per_slot, long slot_stride) {
+                                          int* __restrict__ err, int rows_per_slot, long slot_stride,
+                                          unsigned long long* __restrict__ adv_state, unsigned long long inc0,
+                                          unsigned long long inc1) {
     const int m = blockIdx.x;
+    // optional: the per-iteration device state (Philox counter, permutation cursor) advanced by this launch instead of by
+    // one of its own (wfd_iter_advance); nothing in this kernel reads it
+    if (adv_state && m == 0 && threadIdx.x == 0) { adv_state[0] += inc0; adv_state[1] += inc1; }
     // output rows of slot s = m / rows_per_slot start slot_stride floats after those of slot s - 1
     if (rows_per_slot > 0) out += (long)(m / rows_per_slot) * slot_stride - (long)(m / rows_per_slot) * rows_per_slot * ldo;
     const float y0 = 1.0f / (1.0f + expf(-(slab_sum(P, ns, ss, (long)m * ldp) + bias[0])));
@@ -1262,7 +1267,7 @@ int wfd_ep_sigmoid_lenmask(const float* P, int ns, long ss, int ldp, int M, int 
                            float smin, float* out, int ldo, int* idx, int* err, void* stream) {
     if (!P || !bias || !out || !idx || !err) return WFD_ERR_ARG;
     hipLaunchKernelGGL(ep_sigmoid_lenmask_kernel, dim3(M), dim3(512), 0, (hipStream_t)stream, P, ns, ss, ldp, S, bias,
-                       range, smin, out, ldo, idx, err, 0, 0l);
+                       range, smin, out, ldo, idx, err, 0, 0l, (unsigned long long*)nullptr, 0ull, 0ull);
     WFD_CHECK_LAUNCH();
     return WFD_OK;
 }
@@ -1273,7 +1278,20 @@ int wfd_ep_sigmoid_lenmask_slots(const float* P, int ns, long ss, int ldp, int M
                                  void* stream) {
     if (!P || !bias || !out || !idx || !err || rows_per_slot <= 0 || M % rows_per_slot) return WFD_ERR_ARG;
     hipLaunchKernelGGL(ep_sigmoid_lenmask_kernel, dim3(M), dim3(512), 0, (hipStream_t)stream, P, ns, ss, ldp, S, bias,
-                       range, smin, out, ldo, idx, err, rows_per_slot, slot_stride);
+                       range, smin, out, ldo, idx, err, rows_per_slot, slot_stride, (unsigned long long*)nullptr, 0ull, 0ull);
+    WFD_CHECK_LAUNCH();
+    return WFD_OK;
+}
+
+// the same, and the launch also advances the device iteration state (wfd_iter_advance folded in: one launch fewer at the
+// end of a group's stacked generator forward)
+int wfd_ep_sigmoid_lenmask_slots_adv(const float* P, int ns, long ss, int ldp, int M, int S, const float* bias, float range,
+                                     float smin, float* out, int ldo, int rows_per_slot, long slot_stride, int* idx, int* err,
+                                     unsigned long long* state, unsigned long long inc0, unsigned long long inc1,
+                                     void* stream) {
+    if (!P || !bias || !out || !idx || !err || !state || rows_per_slot <= 0 || M % rows_per_slot) return WFD_ERR_ARG;
+    hipLaunchKernelGGL(ep_sigmoid_lenmask_kernel, dim3(M), dim3(512), 0, (hipStream_t)stream, P, ns, ss, ldp, S, bias,
+                       range, smin, out, ldo, idx, err, rows_per_slot, slot_stride, state, inc0, inc1);
     WFD_CHECK_LAUNCH();
     return WFD_OK;
 }

@@ -44,14 +44,14 @@ struct MaskSlots {
     unsigned long long seed[8];
     unsigned long long base[8];
 };
-__global__ void rng_dropout_mask_slots_kernel(MaskSlots a, float p, const unsigned long long* __restrict__ state) {
-    const int s = blockIdx.y;
+__device__ __forceinline__ void mask_slot_body(const MaskSlots& a, int s, long bx, long nbx, float p,
+                                               const unsigned long long* __restrict__ state) {
     float* __restrict__ out = a.out[s];
     const long n = a.n[s];
     const unsigned long long seed = a.seed[s], offset = (state ? state[0] : 0ull) + a.base[s];
     const float keep = 1.0f / (1.0f - p);
-    const long stride = (long)gridDim.x * blockDim.x;
-    for (long q = (long)blockIdx.x * blockDim.x + threadIdx.x; q * 4 < n; q += stride) {
+    const long stride = nbx * blockDim.x;
+    for (long q = bx * blockDim.x + threadIdx.x; q * 4 < n; q += stride) {
         const unsigned long long c = offset + (unsigned long long)q;
         const uint4 r = philox4x32_10(make_uint4((uint32_t)c, (uint32_t)(c >> 32), 0x6d61736bu, 0u),
                                       make_uint2((uint32_t)seed, (uint32_t)(seed >> 32)));
@@ -61,14 +61,16 @@ __global__ void rng_dropout_mask_slots_kernel(MaskSlots a, float p, const unsign
             if (q * 4 + k < n) out[q * 4 + k] = v[k];
     }
 }
+__global__ void rng_dropout_mask_slots_kernel(MaskSlots a, float p, const unsigned long long* __restrict__ state) {
+    mask_slot_body(a, blockIdx.y, blockIdx.x, gridDim.x, p, state);
+}
 
 // standard normal into rows of a strided matrix: out[m][0..Z) (Box-Muller on Philox uniforms)
-__global__ void rng_normal_rows_kernel(float* __restrict__ out, int ld, int M, int Z, unsigned long long seed,
-                                       const unsigned long long* __restrict__ state, unsigned long long base) {
-    const unsigned long long offset = (state ? state[0] : 0ull) + base;
+__device__ __forceinline__ void normal_rows_body(float* __restrict__ out, int ld, int M, int Z, unsigned long long seed,
+                                                 unsigned long long offset, long bx, long nbx) {
     const long total4 = ((long)M * Z + 3) / 4;
-    const long stride = (long)gridDim.x * blockDim.x;
-    for (long q = (long)blockIdx.x * blockDim.x + threadIdx.x; q < total4; q += stride) {
+    const long stride = nbx * blockDim.x;
+    for (long q = bx * blockDim.x + threadIdx.x; q < total4; q += stride) {
         const unsigned long long c = offset + (unsigned long long)q;
         const uint4 r = philox4x32_10(make_uint4((uint32_t)c, (uint32_t)(c >> 32), 0x6e6f726du, 0u),
                                       make_uint2((uint32_t)seed, (uint32_t)(seed >> 32)));
@@ -83,44 +85,72 @@ __global__ void rng_normal_rows_kernel(float* __restrict__ out, int ld, int M, i
         }
     }
 }
+__global__ void rng_normal_rows_kernel(float* __restrict__ out, int ld, int M, int Z, unsigned long long seed,
+                                       const unsigned long long* __restrict__ state, unsigned long long base) {
+    normal_rows_body(out, ld, M, Z, seed, (state ? state[0] : 0ull) + base, blockIdx.x, gridDim.x);
+}
 
 // Assemble one training batch on device (replaces the DataLoader + np.eye one-hot of
 // src/mlp_df_wgan_train.py:184-186):  for b < B:
 //   real[b][0..S) = X[idx[b]][0..S);  real[b][S..S+C) = onehot(y[idx[b]]);  fake[b][S..S+C) = same one-hot
 //   zin[b][Z..Z+C) = same one-hot;  labels_out[b] = y[idx[b]]
-__global__ void gather_batch_kernel(const float* __restrict__ X, int ldX, const int* __restrict__ y,
-                                    const long long* __restrict__ idx, const unsigned long long* __restrict__ state,
-                                    long n_idx, long n_rows, long row_offset, int S, int C, float* __restrict__ real,
-                                    float* __restrict__ fake, int ldd, float* __restrict__ zin, int ldz, int Z,
-                                    int* __restrict__ labels_out, int rows_per_slot, long slot_stride,
-                                    long slot_idx_stride) {
-    int b = blockIdx.x;
-    long pos = row_offset + b;
-    if (rows_per_slot > 0) {
+struct GatherArgs {
+    const float* X; int ldX; const int* y; const long long* idx; const unsigned long long* state;
+    long n_idx, n_rows, row_offset; int S, C; float* real; float* fake; int ldd; float* zin; int ldz, Z;
+    int* labels_out; int rows_per_slot; long slot_stride, slot_idx_stride;
+};
+__device__ __forceinline__ void gather_row_body(const GatherArgs& a, int b) {
+    float* __restrict__ real = a.real;
+    float* __restrict__ fake = a.fake;
+    float* __restrict__ zin = a.zin;
+    int* __restrict__ labels_out = a.labels_out;
+    long pos = a.row_offset + b;
+    if (a.rows_per_slot > 0) {
         // stacked batches of several iterations: slot s = b / rows_per_slot reads the permutation slot_idx_stride
         // entries further on (= the rows all ranks consume per iteration) and writes its own real / fake buffers;
         // the generator input and the labels are stacked contiguously
-        const int slot = b / rows_per_slot, r = b - slot * rows_per_slot;
-        pos = row_offset + (long)slot * slot_idx_stride + r;
-        real += (long)slot * slot_stride;
-        if (fake) fake += (long)slot * slot_stride;
-        if (zin) zin += (long)slot * rows_per_slot * ldz;
-        if (labels_out) labels_out += slot * rows_per_slot;
+        const int slot = b / a.rows_per_slot, r = b - slot * a.rows_per_slot;
+        pos = a.row_offset + (long)slot * a.slot_idx_stride + r;
+        real += (long)slot * a.slot_stride;
+        if (fake) fake += (long)slot * a.slot_stride;
+        if (zin) zin += (long)slot * a.rows_per_slot * a.ldz;
+        if (labels_out) labels_out += slot * a.rows_per_slot;
         b = r;
     }
     // the cursor wraps inside the permutation and the row index is clamped: a stale cursor can never make
     // this kernel read outside the dataset
-    long long src = idx[((state ? (long long)state[1] : 0ll) + pos) % n_idx];
-    src = src < 0 ? 0 : (src >= n_rows ? n_rows - 1 : src);
-    const int lab = y[src];
-    for (int j = threadIdx.x; j < S; j += blockDim.x) real[(long)b * ldd + j] = X[src * ldX + j];
+    long long src = a.idx[((a.state ? (long long)a.state[1] : 0ll) + pos) % a.n_idx];
+    src = src < 0 ? 0 : (src >= a.n_rows ? a.n_rows - 1 : src);
+    const int lab = a.y[src];
+    const int S = a.S, C = a.C, ldd = a.ldd;
+    for (int j = threadIdx.x; j < S; j += blockDim.x) real[(long)b * ldd + j] = a.X[src * a.ldX + j];
     for (int c = threadIdx.x; c < C; c += blockDim.x) {
         const float v = c == lab ? 1.f : 0.f;
         real[(long)b * ldd + S + c] = v;
         if (fake) fake[(long)b * ldd + S + c] = v;
-        if (zin) zin[(long)b * ldz + Z + c] = v;
+        if (zin) zin[(long)b * a.ldz + a.Z + c] = v;
     }
     if (threadIdx.x == 0 && labels_out) labels_out[b] = lab;
+}
+__global__ void gather_batch_kernel(GatherArgs a) { gather_row_body(a, blockIdx.x); }
+
+// Everything a group of n_critic iterations draws before its first product, in ONE launch: the dropout keep-masks of its
+// critic passes and of its G-step (blocks [0, mblocks * nslots)), the gathered real batches with their one-hot columns
+// (the next gblocks blocks, one per row), and the generator's normal inputs (the last zblocks).  The three parts write
+// disjoint memory; each is the body of the kernel it replaces.
+struct GroupInputs {
+    MaskSlots m; int nslots, mblocks; float p; const unsigned long long* mstate;
+    GatherArgs g; int gblocks;
+    unsigned long long zseed; int zblocks, zrows;
+};
+__global__ void group_inputs_kernel(GroupInputs a) {
+    int b = blockIdx.x;
+    const int nm = a.mblocks * a.nslots;
+    if (b < nm) { mask_slot_body(a.m, b / a.mblocks, b % a.mblocks, a.mblocks, a.p, a.mstate); return; }
+    b -= nm;
+    if (b < a.gblocks) { gather_row_body(a.g, b); return; }
+    b -= a.gblocks;
+    normal_rows_body(a.g.zin, a.g.ldz, a.zrows, a.g.Z, a.zseed, a.g.state ? a.g.state[0] : 0ull, b, a.zblocks);
 }
 
 // z rows and the dropout keep-masks of one step in a single launch (same streams as the two kernels above:
@@ -504,8 +534,8 @@ int wfd_gather_batch(const float* X, int ldX, const int* y, const long long* idx
                      long n_idx, long n_rows, long row_offset, int B, int S, int C, float* real, float* fake, int ldd,
                      float* zin, int ldz, int Z, int* labels_out, void* stream) {
     if (!X || !y || !idx || !real || B <= 0 || n_idx <= 0 || n_rows <= 0 || row_offset < 0) return WFD_ERR_ARG;
-    hipLaunchKernelGGL(gather_batch_kernel, dim3(B), dim3(256), 0, (hipStream_t)stream, X, ldX, y, idx, state, n_idx, n_rows,
-                       row_offset, S, C, real, fake, ldd, zin, ldz, Z, labels_out, 0, 0l, 0l);
+    const GatherArgs a{X, ldX, y, idx, state, n_idx, n_rows, row_offset, S, C, real, fake, ldd, zin, ldz, Z, labels_out, 0, 0l, 0l};
+    hipLaunchKernelGGL(gather_batch_kernel, dim3(B), dim3(256), 0, (hipStream_t)stream, a);
     WFD_CHECK_LAUNCH();
     return WFD_OK;
 }
@@ -515,8 +545,45 @@ int wfd_gather_batch_slots(const float* X, int ldX, const int* y, const long lon
                            float* real, float* fake, int ldd, long slot_stride, float* zin, int ldz, int Z,
                            int* labels_out, void* stream) {
     if (!X || !y || !idx || !real || B <= 0 || slots <= 0 || n_idx <= 0 || n_rows <= 0 || row_offset < 0) return WFD_ERR_ARG;
-    hipLaunchKernelGGL(gather_batch_kernel, dim3(B * slots), dim3(256), 0, (hipStream_t)stream, X, ldX, y, idx, state, n_idx,
-                       n_rows, row_offset, S, C, real, fake, ldd, zin, ldz, Z, labels_out, B, slot_stride, slot_idx_stride);
+    const GatherArgs a{X, ldX, y, idx, state, n_idx, n_rows, row_offset, S, C, real, fake, ldd, zin, ldz, Z, labels_out, B,
+                       slot_stride, slot_idx_stride};
+    hipLaunchKernelGGL(gather_batch_kernel, dim3(B * slots), dim3(256), 0, (hipStream_t)stream, a);
+    WFD_CHECK_LAUNCH();
+    return WFD_OK;
+}
+
+// wfd_rng_dropout_mask_slots + wfd_gather_batch_slots + wfd_rng_normal_rows (rows B * slots of zin, columns [0, Z), key zseed,
+// counter state[0]) as one launch; same results as the three
+int wfd_group_inputs(const unsigned long long* mslots, int nslots, float p, const unsigned long long* mask_state,
+                     const float* X, int ldX, const int* y, const long long* idx, const unsigned long long* state,
+                     long n_idx, long n_rows, long row_offset, int B, int slots, long slot_idx_stride, int S, int C,
+                     float* real, float* fake, int ldd, long slot_stride, float* zin, int ldz, int Z, int* labels_out,
+                     unsigned long long zseed, void* stream) {
+    if (!mslots || nslots < 1 || nslots > 8 || p < 0.f || p >= 1.f) return WFD_ERR_ARG;
+    if (!X || !y || !idx || !real || !zin || B <= 0 || slots <= 0 || n_idx <= 0 || n_rows <= 0 || row_offset < 0 || Z <= 0 ||
+        ldz < Z) return WFD_ERR_ARG;
+    GroupInputs a{};
+    long nmax = 0;
+    for (int s = 0; s < nslots; ++s) {
+        a.m.out[s] = reinterpret_cast<float*>(mslots[4 * s]);
+        a.m.n[s] = (long)mslots[4 * s + 1];
+        a.m.seed[s] = mslots[4 * s + 2];
+        a.m.base[s] = mslots[4 * s + 3];
+        if (!a.m.out[s] || a.m.n[s] <= 0) return WFD_ERR_ARG;
+        if (a.m.n[s] > nmax) nmax = a.m.n[s];
+    }
+    long mb = (nmax / 4 + 255) / 256;
+    if (mb > 1024) mb = 1024;
+    if (mb < 1) mb = 1;
+    a.nslots = nslots; a.mblocks = (int)mb; a.p = p; a.mstate = mask_state;
+    a.g = GatherArgs{X, ldX, y, idx, state, n_idx, n_rows, row_offset, S, C, real, fake, ldd, zin, ldz, Z, labels_out, B,
+                     slot_stride, slot_idx_stride};
+    a.gblocks = B * slots;
+    a.zseed = zseed; a.zrows = B * slots;
+    long zb = (((long)a.zrows * Z + 3) / 4 + 255) / 256;
+    if (zb > 256) zb = 256;
+    a.zblocks = (int)zb;
+    hipLaunchKernelGGL(group_inputs_kernel, dim3((unsigned)(mb * nslots + a.gblocks + zb)), dim3(256), 0, (hipStream_t)stream, a);
     WFD_CHECK_LAUNCH();
     return WFD_OK;
 }

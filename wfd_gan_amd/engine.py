@@ -1358,17 +1358,27 @@ class GroupedTrainer:
             ge = self.e[n - 1]
             slots += [ge.buf["gMKflat"].data_ptr(), ge.buf["gMKflat"].numel(), (ge.seed + 4 * eng.GOLD) & M64, n * inc]
             self._mask_slots = (ctypes.c_ulonglong * len(slots))(*slots)
-            p.add(L.rng_dropout_mask_slots, self._mask_slots, len(slots) // 4, 0.2, eng.iter_state.data_ptr())
         state = eng.gf_state.data_ptr()
         xc = st["XC"]                                   # [n][2*Mslot][ldx]
         slot_stride = xc.stride(0)
         real0, fake0 = self.e[0].real_rows, self.e[0].fake_rows
-        p.add(L.gather_batch_slots, ptr(eng.data_X), S, ptr(eng.data_y), ptr(eng.perm), state, eng.N, eng.N, eng.row_offset,
-              B, n, eng.cursor_step, S, C, ptr(real0), ptr(fake0), eng.ldx, slot_stride, ptr(st["ZIN"]), eng.ldz, Z,
-              ptr(st["labels"]))
-        # its own Philox key: the single-iteration plans (fast_d, key seed + 7 GOLD) count from 0 as well, and the trainer
+        # z has its own Philox key: the single-iteration plans (fast_d, key seed + 7 GOLD) count from 0 as well, and the trainer
         # runs iteration 0 of an epoch on them -- with a shared key iteration 1 would repeat iteration 0's noise
-        p.add(L.rng_normal_rows, ptr(st["ZIN"]), eng.ldz, M, Z, (eng.seed + 13 * eng.GOLD) & (2**64 - 1), state, 0)
+        zseed = (eng.seed + 13 * eng.GOLD) & (2**64 - 1)
+        fold = self.merged_masks and os.environ.get("WFD_HEAD_MERGE", "1") != "0"       # (the switch: same-session A/B)
+        if fold:
+            # masks + gathered batches + z: three independent draws, one launch
+            p.add(L.group_inputs, self._mask_slots, len(slots) // 4, 0.2, eng.iter_state.data_ptr(),
+                  ptr(eng.data_X), S, ptr(eng.data_y), ptr(eng.perm), state, eng.N, eng.N, eng.row_offset,
+                  B, n, eng.cursor_step, S, C, ptr(real0), ptr(fake0), eng.ldx, slot_stride, ptr(st["ZIN"]), eng.ldz, Z,
+                  ptr(st["labels"]), zseed)
+        else:
+            if self.merged_masks:
+                p.add(L.rng_dropout_mask_slots, self._mask_slots, len(slots) // 4, 0.2, eng.iter_state.data_ptr())
+            p.add(L.gather_batch_slots, ptr(eng.data_X), S, ptr(eng.data_y), ptr(eng.perm), state, eng.N, eng.N, eng.row_offset,
+                  B, n, eng.cursor_step, S, C, ptr(real0), ptr(fake0), eng.ldx, slot_stride, ptr(st["ZIN"]), eng.ldz, Z,
+                  ptr(st["labels"]))
+            p.add(L.rng_normal_rows, ptr(st["ZIN"]), eng.ldz, M, Z, zseed, state, 0)
         p.gemm_affine(NT, st["ZIN"], eng.ldz, G["model.0.weight"], eng.Gp.ld["model.0.weight"], M, 512, Z + C, None,
                       G["model.0.bias"], ACT_RELU, st["GH1"], 512)
         prev, kprev = st["GH1"], 512
@@ -1379,9 +1389,15 @@ class GroupedTrainer:
                   ptr(st[f"mean{i}"]), ptr(st[f"m2{i}"]), ptr(st[f"istd{i}"]), 0, 0, 0.1)      # running statistics: see gstep
             prev, kprev = st[f"GH{i}"], width
         s = p.gemm(NT, prev, 2048, G["model.8.weight"], 2048, M, S, 2048)
-        p.add(L.ep_sigmoid_lenmask_slots, s.ptr, s.ns, s.ss, s.ldp, M, S, ptr(G["model.8.bias"]), eng.range_f, eng.smin_f,
-              ptr(fake0), eng.ldx, B, slot_stride, ptr(st["idx"]), ptr(eng.buf["err"]))
-        p.add(L.iter_advance, state, (M * Z + 3) // 4, n * eng.cursor_step)
+        if os.environ.get("WFD_HEAD_MERGE", "1") != "0":
+            # the last launch of the head also advances the z counter and the permutation cursor
+            p.add(L.ep_sigmoid_lenmask_slots_adv, s.ptr, s.ns, s.ss, s.ldp, M, S, ptr(G["model.8.bias"]), eng.range_f, eng.smin_f,
+                  ptr(fake0), eng.ldx, B, slot_stride, ptr(st["idx"]), ptr(eng.buf["err"]), state, (M * Z + 3) // 4,
+                  n * eng.cursor_step)
+        else:
+            p.add(L.ep_sigmoid_lenmask_slots, s.ptr, s.ns, s.ss, s.ldp, M, S, ptr(G["model.8.bias"]), eng.range_f, eng.smin_f,
+                  ptr(fake0), eng.ldx, B, slot_stride, ptr(st["idx"]), ptr(eng.buf["err"]))
+            p.add(L.iter_advance, state, (M * Z + 3) // 4, n * eng.cursor_step)
         return p
 
     def _capture(self):
