@@ -182,6 +182,15 @@ int wfd_rmsprop(float* p, const float* g, float* sq, long n, float lr, float alp
  * gradient's store by wfd_gemm_f32_rmsprop.  Bookkeeping as wfd_rmsprop. */
 int wfd_rmsprop_ranges(float* p, const float* g, float* sq, const long* ranges, int nranges, float lr, float alpha, float eps,
                        unsigned long long* state, unsigned long long inc0, unsigned long long inc1, void* stream);
+/* the small work that ends a G-step whose matrices were updated in their gradients' stores, as ONE launch:
+ * wfd_colsum_multi_rmsprop (desc, nseg, cs_blocks: the first layer's bias gradient and its step; also does the step's
+ * bookkeeping) + wfd_rmsprop_ranges on `ranges` (the remaining vectors; optimizer_G.step(), src/mlp_df_wgan_train.py:275)
+ * + wfd_bn_running_update_layers (meanA ... nupd_last; meanA = NULL leaves that part out).  Same values as the three. */
+int wfd_g_end(const long long* desc, int nseg, int cs_blocks, const float* gbase, float* pbase, float* sqbase, long numel,
+              const long* ranges, int nranges, float lr, float alpha, float eps, unsigned long long* state,
+              unsigned long long inc0, unsigned long long inc1, const float* meanA, const float* m2A, int NA, float* rmeanA,
+              float* rvarA, const float* meanB, const float* m2B, int NB, float* rmeanB, float* rvarB, float count,
+              float momentum, int groups, int nupd_last, void* stream);
 
 /* loss.backward() + optimizer.step() for ONE weight matrix (src/mlp_df_wgan_train.py:229-230, 273-275): the gradient
  * g = (M,N,K) product of the given layout (2 = TN: dW = dZ^T H over the batch rows) is consumed in the store,

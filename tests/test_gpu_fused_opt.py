@@ -206,12 +206,14 @@ def test_grouped_observer_ahead_is_bit_identical(graphs):
         assert torch.equal(a, b), f"tensor {k} differs between the two schedules"
 
 
+@pytest.mark.parametrize("switch,part,fewer", [("WFD_HEAD_MERGE", "head", 3), ("WFD_G_END_MERGE", "gstep", 2)])
 @pytest.mark.parametrize("graphs", [False, True])
-def test_grouped_head_merged_launches_are_bit_identical(graphs, monkeypatch):
-    """The head of a group with its three independent draws (dropout masks of every pass, gathered batches + one-hot
+def test_grouped_head_merged_launches_are_bit_identical(graphs, switch, part, fewer, monkeypatch):
+    """Small independent launches of a group sharing one launch, against one launch each.  WFD_HEAD_MERGE: the head of a group with its three independent draws (dropout masks of every pass, gathered batches + one-hot
     columns, z) in one launch (wfd_group_inputs) and the state advance folded into the last launch
-    (wfd_ep_sigmoid_lenmask_slots_adv), against one launch each: 3 launches fewer, every state tensor bit-identical after
-    three groups (the second and third group see the advanced counter / cursor)."""
+    (wfd_ep_sigmoid_lenmask_slots_adv): 3 launches fewer.  WFD_G_END_MERGE: the end of the fused G-step (first layer's bias
+    gradient and its RMSprop step, the other vectors' steps, the BatchNorm running statistics) as wfd_g_end: 2 fewer.
+    Every state tensor bit-identical after three groups (the second and third group see the advanced counter / cursor)."""
     from wfd_gan_amd.engine import GroupedTrainer, TrainEngine
     S, C, Z, B = 101, 6, 24, 16
     X, y = O.synth_dataset(C, 30, S - 1, 10, 13, 122, seed=1)
@@ -220,14 +222,14 @@ def test_grouped_head_merged_launches_are_bit_identical(graphs, monkeypatch):
     Xs = torch.from_numpy(X * scale + min_).float()
     out, launches = [], []
     for merge in ("1", "0"):
-        monkeypatch.setenv("WFD_HEAD_MERGE", merge)
+        monkeypatch.setenv(switch, merge)
         st = O.make_state(S, C, Z, dmin[0], dmax[0], seed=2, df_seed=3)
         O.perturb_df_bn(st.DF, 4)
         eng = TrainEngine(S, C, Z, B, st.scaler_min, st.scaler_max, {k: v.detach() for k, v in st.G.items()},
                           {k: v.detach() for k, v in st.D.items()}, st.DF, device=DEV, seed=11, fuse_opt=True)
         eng.attach_dataset(Xs, torch.from_numpy(y), shuffle_seed=5)
         grp = GroupedTrainer(eng, graphs=graphs)
-        launches.append(len(grp.head.calls))
+        launches.append(len(getattr(grp, part).calls))
         for _ in range(3):
             grp.run_group()
         torch.cuda.synchronize()
@@ -235,9 +237,9 @@ def test_grouped_head_merged_launches_are_bit_identical(graphs, monkeypatch):
                     eng.gf_state.clone(), eng.buf["dacc"].clone(), eng.buf["gacc"].clone(), grp.stacked["ZIN"].clone(),
                     grp.stacked["labels"].clone(), grp.stacked["XC"].clone(), grp.slot(2).buf["LOG"].clone()]
                    + [e.buf["MKflat"].clone() for e in grp.e] + [v.clone() for v in eng.Gbuf.values()])
-    assert launches[1] - launches[0] == 3
+    assert launches[1] - launches[0] == fewer
     for k, (a, b) in enumerate(zip(*out)):
-        assert torch.equal(a, b), f"tensor {k} differs between the merged and the one-launch-each head"
+        assert torch.equal(a, b), f"tensor {k} differs between the merged and the one-launch-each form"
 
 
 @pytest.mark.parametrize("name", ["tiny", "cfg2"])

@@ -322,14 +322,14 @@ __global__ void colsum_kernel(const float* __restrict__ X, int ldx, int M, int N
 struct ColsumOpt { const float* gbase; float* pbase; float* sqbase; long numel; float lr, alpha, eps;
                    unsigned long long* state; unsigned long long inc0, inc1; };
 template <bool OPT>
-__global__ void colsum_multi_kernel(const long long* __restrict__ desc, int nseg, ColsumOpt o) {
-    __shared__ float red[RG][CT];
+__device__ __forceinline__ void colsum_multi_body(const long long* __restrict__ desc, int nseg, const ColsumOpt& o, int bx,
+                                                  float (*red)[CT]) {
     if constexpr (OPT) {
-        if (o.state && blockIdx.x == 0 && threadIdx.x == 0 && threadIdx.y == 0) { o.state[0] += o.inc0; o.state[1] += o.inc1; }
+        if (o.state && bx == 0 && threadIdx.x == 0 && threadIdx.y == 0) { o.state[0] += o.inc0; o.state[1] += o.inc1; }
     }
     int sgi = 0;
     for (int k = 1; k < nseg; ++k)
-        if ((int)desc[k * 11 + 9] <= (int)blockIdx.x) sgi = k;
+        if ((int)desc[k * 11 + 9] <= bx) sgi = k;
     const long long* d = desc + sgi * 11;
     const float* X = reinterpret_cast<const float*>(d[0]);
     const int ldx = (int)d[1];
@@ -340,7 +340,7 @@ __global__ void colsum_multi_kernel(const long long* __restrict__ desc, int nseg
     const int M = (int)d[6], N = (int)d[7];
     float* out = reinterpret_cast<float*>(d[8]);
     float* acc = reinterpret_cast<float*>(d[10]);
-    const int n = ((int)blockIdx.x - (int)d[9]) * CT + threadIdx.x;
+    const int n = (bx - (int)d[9]) * CT + threadIdx.x;
     float a = 0.f;
     if (n < N) {
         a = col_partial(X, ldx, rs, M, n, threadIdx.y, a);
@@ -360,6 +360,11 @@ __global__ void colsum_multi_kernel(const long long* __restrict__ desc, int nseg
             }
         }
     }
+}
+template <bool OPT>
+__global__ void colsum_multi_kernel(const long long* __restrict__ desc, int nseg, ColsumOpt o) {
+    __shared__ float red[RG][CT];
+    colsum_multi_body<OPT>(desc, nseg, o, blockIdx.x, red);
 }
 
 // RMSprop (torch defaults: alpha .99, eps 1e-8, no momentum, not centered, wd 0), one flat pass
@@ -396,11 +401,8 @@ __global__ void rmsprop_kernel(float* __restrict__ p, const float* __restrict__ 
 // The same update on up to 8 element ranges [beg, end) of the flat buffers: the vectors (biases, BatchNorm affine, the
 // critic's head) of a network whose weight matrices were updated in their gradient's store (wfd_gemm_f32_rmsprop).
 struct RmsRanges { long beg[8], end[8]; int n; };
-__global__ void rmsprop_ranges_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ sq, RmsRanges r,
-                                      float lr, float alpha, float eps, unsigned long long* __restrict__ state,
-                                      unsigned long long inc0, unsigned long long inc1) {
-    if (state && blockIdx.x == 0 && threadIdx.x == 0) { state[0] += inc0; state[1] += inc1; }
-    long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+__device__ __forceinline__ void rmsprop_ranges_body(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ sq,
+                                                    const RmsRanges& r, float lr, float alpha, float eps, long i) {
     for (int k = 0; k < r.n; ++k) {
         const long len = r.end[k] - r.beg[k];
         if (i < len) {
@@ -413,6 +415,12 @@ __global__ void rmsprop_ranges_kernel(float* __restrict__ p, const float* __rest
         }
         i -= len;
     }
+}
+__global__ void rmsprop_ranges_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ sq, RmsRanges r,
+                                      float lr, float alpha, float eps, unsigned long long* __restrict__ state,
+                                      unsigned long long inc0, unsigned long long inc1) {
+    if (state && blockIdx.x == 0 && threadIdx.x == 0) { state[0] += inc0; state[1] += inc1; }
+    rmsprop_ranges_body(p, g, sq, r, lr, alpha, eps, (long)blockIdx.x * blockDim.x + threadIdx.x);
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -623,9 +631,8 @@ __global__ void bn_running_update_kernel(const float* __restrict__ mean, const f
 // layer; its `groups` batches are applied in order, the last one `nupd_last` times (the G-step's second forward of the same
 // batch, src/mlp_df_wgan_train.py:240).  Element for element the operations of bn_running_update_kernel applied batch by batch.
 struct BnLayer { const float* mean; const float* m2; float* rmean; float* rvar; int N; };
-__global__ void bn_running_update_layers_kernel(BnLayer a, BnLayer b, float count, float momentum, int groups, int nupd_last) {
-    const BnLayer& l = blockIdx.y ? b : a;
-    const int n = blockIdx.x * blockDim.x + threadIdx.x;
+__device__ __forceinline__ void bn_running_layer_body(const BnLayer& l, int n, float count, float momentum, int groups,
+                                                      int nupd_last) {
     if (n >= l.N) return;
     float rm = l.rmean[n], rv = l.rvar[n];
     for (int g = 0; g < groups; ++g) {
@@ -638,6 +645,32 @@ __global__ void bn_running_update_layers_kernel(BnLayer a, BnLayer b, float coun
     }
     l.rmean[n] = rm;
     l.rvar[n] = rv;
+}
+__global__ void bn_running_update_layers_kernel(BnLayer a, BnLayer b, float count, float momentum, int groups, int nupd_last) {
+    bn_running_layer_body(blockIdx.y ? b : a, blockIdx.x * blockDim.x + threadIdx.x, count, momentum, groups, nupd_last);
+}
+
+// The small work that ends a G-step whose weight matrices were updated in their gradients' stores, as ONE launch:
+//   blocks [0, cs_blocks)            column sums (the first layer's bias gradient) with their RMSprop step   = colsum_multi<OPT>
+//   the next rr_blocks               RMSprop on the other vector ranges of the flat buffers                   = rmsprop_ranges
+//   the last 2 * bn_blocks           running statistics of the two BatchNorm layers, all stacked batches      = bn_running_update_layers
+// The three parts touch disjoint memory and each is the body of the kernel it replaces.  Blocks are (CT, RG) threads.
+struct BnRun { BnLayer a, b; float count, momentum; int groups, nupd_last, bn_blocks; };
+__global__ void g_end_kernel(const long long* __restrict__ desc, int nseg, int cs_blocks, ColsumOpt o, RmsRanges r,
+                             int rr_blocks, BnRun bn) {
+    __shared__ float red[RG][CT];
+    int b = blockIdx.x;
+    if (b < cs_blocks) { colsum_multi_body<true>(desc, nseg, o, b, red); return; }
+    b -= cs_blocks;
+    const int tid = threadIdx.y * CT + threadIdx.x;
+    if (b < rr_blocks) {
+        rmsprop_ranges_body(o.pbase, o.gbase, o.sqbase, r, o.lr, o.alpha, o.eps, (long)b * (CT * RG) + tid);
+        return;
+    }
+    b -= rr_blocks;
+    if (bn.bn_blocks > 0)
+        bn_running_layer_body(b / bn.bn_blocks ? bn.b : bn.a, (b % bn.bn_blocks) * (CT * RG) + tid, bn.count, bn.momentum,
+                              bn.groups, bn.nupd_last);
 }
 
 // BatchNorm backward through ReLU.  dy = sumP o [H > 0].
@@ -1112,6 +1145,40 @@ int wfd_rmsprop_ranges(float* p, const float* g, float* sq, const long* ranges, 
     if (total <= 0) return WFD_ERR_ARG;
     hipLaunchKernelGGL(rmsprop_ranges_kernel, dim3(cdiv(total, 256)), dim3(256), 0, (hipStream_t)stream, p, g, sq, r, lr, alpha,
                        eps, state, inc0, inc1);
+    WFD_CHECK_LAUNCH();
+    return WFD_OK;
+}
+
+int wfd_g_end(const long long* desc, int nseg, int cs_blocks, const float* gbase, float* pbase, float* sqbase, long numel,
+              const long* ranges, int nranges, float lr, float alpha, float eps, unsigned long long* state,
+              unsigned long long inc0, unsigned long long inc1, const float* meanA, const float* m2A, int NA, float* rmeanA,
+              float* rvarA, const float* meanB, const float* m2B, int NB, float* rmeanB, float* rvarB, float count,
+              float momentum, int groups, int nupd_last, void* stream) {
+    if (!desc || nseg <= 0 || cs_blocks <= 0 || !gbase || !pbase || !sqbase || numel <= 0) return WFD_ERR_ARG;
+    if (!ranges || nranges < 1 || nranges > 8) return WFD_ERR_ARG;
+    ColsumOpt o{gbase, pbase, sqbase, numel, lr, alpha, eps, state, inc0, inc1};
+    RmsRanges r{};
+    long total = 0;
+    for (int k = 0; k < nranges; ++k) {
+        r.beg[k] = ranges[2 * k]; r.end[k] = ranges[2 * k + 1];
+        if (r.beg[k] < 0 || r.end[k] < r.beg[k] || r.end[k] > numel) return WFD_ERR_ARG;
+        total += r.end[k] - r.beg[k];
+    }
+    r.n = nranges;
+    if (total <= 0) return WFD_ERR_ARG;
+    BnRun bn{};
+    if (meanA) {          // optional part
+        if (!m2A || !rmeanA || !rvarA || !meanB || !m2B || !rmeanB || !rvarB || NA < 1 || NB < 1 || groups < 1 ||
+            nupd_last < 0 || count <= 1.f)
+            return WFD_ERR_ARG;
+        bn.a = BnLayer{meanA, m2A, rmeanA, rvarA, NA};
+        bn.b = BnLayer{meanB, m2B, rmeanB, rvarB, NB};
+        bn.count = count; bn.momentum = momentum; bn.groups = groups; bn.nupd_last = nupd_last;
+        bn.bn_blocks = cdiv(NA > NB ? NA : NB, CT * RG);
+    }
+    const int rr_blocks = cdiv(total, CT * RG);
+    hipLaunchKernelGGL(g_end_kernel, dim3(cs_blocks + rr_blocks + 2 * bn.bn_blocks), dim3(CT, RG), 0, (hipStream_t)stream, desc,
+                       nseg, cs_blocks, o, r, rr_blocks, bn);
     WFD_CHECK_LAUNCH();
     return WFD_OK;
 }

@@ -788,10 +788,14 @@ class TrainEngine:
         # generator(z, c) of :240 reproduces the same activations; only its BN running-stat update is new.
         src = bn_stacked if bn_stacked is not None else b
         groups = bn_stacked["mean2"].shape[0] if bn_stacked is not None else 1
-        p.add(self.L.bn_running_update_layers, ptr(src["mean2"]), ptr(src["m22"]), 1024,
-              ptr(self.Gbuf["model.3.running_mean"]), ptr(self.Gbuf["model.3.running_var"]), ptr(src["mean3"]), ptr(src["m23"]),
-              2048, ptr(self.Gbuf["model.6.running_mean"]), ptr(self.Gbuf["model.6.running_var"]), float(self.Bg), 0.1, groups,
-              2 if bn_stacked is not None else 1)
+        bn_run = (ptr(src["mean2"]), ptr(src["m22"]), 1024,
+                  ptr(self.Gbuf["model.3.running_mean"]), ptr(self.Gbuf["model.3.running_var"]), ptr(src["mean3"]), ptr(src["m23"]),
+                  2048, ptr(self.Gbuf["model.6.running_mean"]), ptr(self.Gbuf["model.6.running_var"]), float(self.Bg), 0.1, groups,
+                  2 if bn_stacked is not None else 1)
+        # fused single-GPU G-step: the running statistics ride on the step's last launch (nothing reads them in between)
+        end_merge = self.fuse_g and os.environ.get("WFD_G_END_MERGE", "1") != "0"          # (the switch: same-session A/B)
+        if not end_merge:
+            p.add(self.L.bn_running_update_layers, *bn_run)
         # side lane: critic pass on the fake rows + its input-gradient chain (slabs stay in the side workspace until
         # g_out_bwd reads them); main lane: the DF observer forward.  They meet at the masked CE.
         merged = self.g_merge and observer_forward
@@ -827,7 +831,8 @@ class TrainEngine:
             s = p.gemm(NN, b["GDZ3"], 2048, Gp["model.5.weight"], 1024, B, 1024, 2048)
             self._bn_bwd(p, s, 2, "model.2", "model.3", 1024)
             p.gemm_mul(NN, b["GDZ2"], 1024, Gp["model.2.weight"], 512, B, 512, 1024, b["GH1"], 512, DM_RELU, None, b["GDZ1"], 512)
-            p.add(self.L.colsum, ptr(b["GDZ1"]), 512, B, 512, 0, ptr(G.g["model.0.bias"]), 0)
+            if not end_merge:
+                p.add(self.L.colsum, ptr(b["GDZ1"]), 512, B, 512, 0, ptr(G.g["model.0.bias"]), 0)
             # the activation-gradient chain is done (it read W_8, W_5, W_2): all four weight gradients, one launch
             p.gemm_rms_multi([
                 (b["GDZ4"], self.lds4, b["GH3"], 2048, S, 2048, B, Gp["model.8.weight"], 2048, G.s["model.8.weight"]),
@@ -835,7 +840,18 @@ class TrainEngine:
                 (b["GDZ2"], 1024, b["GH1"], 512, 1024, 512, B, Gp["model.2.weight"], 512, G.s["model.2.weight"]),
                 (b["GDZ1"], 512, b["ZIN"], self.ldz, 512, Z + C, B, Gp["model.0.weight"], G.ld["model.0.weight"],
                  G.s["model.0.weight"])], self.lr)
-            self._optimizer(p, G, True, st if fast else 0, self._rng_inc() if fast else 0, 0)
+            if end_merge:
+                # first layer's bias gradient + its step, the other vectors' steps, the BN running statistics: one launch
+                desc = torch.tensor([[ptr(b["GDZ1"]), 512, 0, 0, 0, 0, B, 512, ptr(G.g["model.0.bias"]), 0, 0]],
+                                    dtype=torch.int64, device=self.dev)
+                b0 = G.offsets["model.0.bias"]
+                flat = [v for r in G.vector_ranges() if r[0] != b0 for v in r]
+                arr = (ctypes.c_long * len(flat))(*flat)
+                p.keep += [desc, arr]
+                p.add(self.L.g_end, ptr(desc), 1, 512 // 32, ptr(G.grad), ptr(G.flat), ptr(G.sq), G.numel, arr, len(flat) // 2,
+                      self.lr, 0.99, 1e-8, st if fast else 0, self._rng_inc() if fast else 0, 0, *bn_run)
+            else:
+                self._optimizer(p, G, True, st if fast else 0, self._rng_inc() if fast else 0, 0)
             return p
         s = p.gemm_pair((b["GDZ4"], self.lds4, b["GH3"], 2048, S, 2048, B, G.g["model.8.weight"], 2048),
                         (NN, b["GDZ4"], self.lds4, Gp["model.8.weight"], 2048, B, 2048, S), pair=pr)
