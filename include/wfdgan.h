@@ -207,6 +207,14 @@ int wfd_gemm_f32_rmsprop(int layout, const float* A, int lda, const float* B, in
  * products must be independent of each other (none reads a P of the list).  Returns 1 when a problem does not fit the
  * fast form (operands not 16-byte aligned, N <= 32, operand mode != f32): launch them one by one then.  Same bits. */
 int wfd_gemm_f32_rmsprop_multi(const long long* desc, int n, float lr, float alpha, float eps, void* stream);
+/* wfd_gemm_f32_rmsprop_multi whose launch also carries wfd_colsum_multi_rmsprop(cs_desc, cs_nseg, cs_blocks, gbase, pbase,
+ * sqbase, numel, lr, alpha, eps, state, inc0, inc1) in its first cs_blocks workgroups: the whole end of a critic step
+ * (d_loss.backward()'s weight, bias and head gradients with optimizer_D.step(), src/mlp_df_wgan_train.py:229-230, the loss
+ * scalars of :215-227 and the step's bookkeeping) as ONE launch.  The column sums must not read the parameter matrices. */
+int wfd_gemm_f32_rmsprop_multi_colsum(const long long* desc, int n, float lr, float alpha, float eps, const long long* cs_desc,
+                                      int cs_nseg, int cs_blocks, const float* gbase, float* pbase, float* sqbase, long numel,
+                                      unsigned long long* state, unsigned long long inc0, unsigned long long inc1,
+                                      void* stream);
 
 /* nn.BatchNorm1d(n, eps=0.8) training forward (src/model.py:23), in two halves so that data-parallel ranks can
  * combine (mean, M2) in between: stats writes Z = sumP + bias and the per-column mean / sum of squared deviations;

@@ -206,13 +206,16 @@ def test_grouped_observer_ahead_is_bit_identical(graphs):
         assert torch.equal(a, b), f"tensor {k} differs between the two schedules"
 
 
-@pytest.mark.parametrize("switch,part,fewer", [("WFD_HEAD_MERGE", "head", 3), ("WFD_G_END_MERGE", "gstep", 2)])
+@pytest.mark.parametrize("switch,part,fewer", [("WFD_HEAD_MERGE", "head", 3), ("WFD_G_END_MERGE", "gstep", 2),
+                                               ("WFD_D_END_MERGE", "rest", 1)])
 @pytest.mark.parametrize("graphs", [False, True])
 def test_grouped_head_merged_launches_are_bit_identical(graphs, switch, part, fewer, monkeypatch):
     """Small independent launches of a group sharing one launch, against one launch each.  WFD_HEAD_MERGE: the head of a group with its three independent draws (dropout masks of every pass, gathered batches + one-hot
     columns, z) in one launch (wfd_group_inputs) and the state advance folded into the last launch
     (wfd_ep_sigmoid_lenmask_slots_adv): 3 launches fewer.  WFD_G_END_MERGE: the end of the fused G-step (first layer's bias
     gradient and its RMSprop step, the other vectors' steps, the BatchNorm running statistics) as wfd_g_end: 2 fewer.
+    WFD_D_END_MERGE: the column sums that end a fused D-step (bias / head gradients with their steps, loss scalars,
+    bookkeeping) in the first workgroups of the weight-gradient launch (wfd_gemm_f32_rmsprop_multi_colsum): 1 fewer per D-step.
     Every state tensor bit-identical after three groups (the second and third group see the advanced counter / cursor)."""
     from wfd_gan_amd.engine import GroupedTrainer, TrainEngine
     S, C, Z, B = 101, 6, 24, 16
@@ -229,11 +232,13 @@ def test_grouped_head_merged_launches_are_bit_identical(graphs, switch, part, fe
                           {k: v.detach() for k, v in st.D.items()}, st.DF, device=DEV, seed=11, fuse_opt=True)
         eng.attach_dataset(Xs, torch.from_numpy(y), shuffle_seed=5)
         grp = GroupedTrainer(eng, graphs=graphs)
-        launches.append(len(getattr(grp, part).calls))
+        plan = getattr(grp, part)
+        launches.append(len((plan[0] if isinstance(plan, list) else plan).calls))
         for _ in range(3):
             grp.run_group()
         torch.cuda.synchronize()
-        out.append([eng.Dp.flat.clone(), eng.Dp.sq.clone(), eng.Gp.flat.clone(), eng.Gp.sq.clone(), eng.iter_state.clone(),
+        out.append([eng.Dp.flat.clone(), eng.Dp.sq.clone(), eng.Dp.grad.clone(), eng.Gp.flat.clone(), eng.Gp.sq.clone(),
+                    eng.iter_state.clone(), grp.slot(1).buf["dstats"].clone(),
                     eng.gf_state.clone(), eng.buf["dacc"].clone(), eng.buf["gacc"].clone(), grp.stacked["ZIN"].clone(),
                     grp.stacked["labels"].clone(), grp.stacked["XC"].clone(), grp.slot(2).buf["LOG"].clone()]
                    + [e.buf["MKflat"].clone() for e in grp.e] + [v.clone() for v in eng.Gbuf.values()])

@@ -269,28 +269,7 @@ __global__ void ep_penalty_row_kernel(const float* __restrict__ P, int ns, long 
     for (int j = threadIdx.x; j < S; j += blockDim.x) GH[(long)m * ldg + j] = coef * grow[j];
 }
 
-// Column-reduction kernels use 32 columns x 16 row groups per workgroup (coalesced 128-B row segments, LDS
-// reduce over the row groups) so that a 64..128-row batch still spreads over N/32 workgroups.
-constexpr int CT = 32, RG = 16;
-
-// sum over this thread's rows m = m0, m0 + RG, ... of X[m][n] * rs[m], eight independent loads in flight per batch
-// (same add order as the plain loop)
-__device__ __forceinline__ float col_partial(const float* __restrict__ X, int ldx, const float* __restrict__ rs, int M,
-                                             int n, int m0, float a) {
-    int m = m0;
-    for (; m + 7 * RG < M; m += 8 * RG) {
-        float x[8], r[8];
-#pragma unroll
-        for (int k = 0; k < 8; ++k) {
-            x[k] = X[(long)(m + k * RG) * ldx + n];
-            r[k] = rs ? rs[m + k * RG] : 1.f;
-        }
-#pragma unroll
-        for (int k = 0; k < 8; ++k) a += x[k] * r[k];
-    }
-    for (; m < M; m += RG) a += X[(long)m * ldx + n] * (rs ? rs[m] : 1.f);
-    return a;
-}
+#include "colsum_body.h"
 
 __device__ __forceinline__ float rg_reduce(float v, float (*red)[CT]) {
     __syncthreads();
@@ -319,8 +298,6 @@ __global__ void colsum_kernel(const float* __restrict__ X, int ldx, int M, int N
 // OPT: an output that lies inside the flat gradient buffer [gbase, gbase + numel) is a parameter gradient: its parameter
 // (same offset in pbase / sqbase) takes its RMSprop step right here (the vectors of a network whose matrices are updated in
 // their gradients' stores), and block 0 does the step's bookkeeping (state[0] += inc0, state[1] += inc1).
-struct ColsumOpt { const float* gbase; float* pbase; float* sqbase; long numel; float lr, alpha, eps;
-                   unsigned long long* state; unsigned long long inc0, inc1; };
 template <bool OPT>
 __device__ __forceinline__ void colsum_multi_body(const long long* __restrict__ desc, int nseg, const ColsumOpt& o, int bx,
                                                   float (*red)[CT]) {

@@ -391,11 +391,20 @@ __global__ __launch_bounds__(NTHREADS) void gemm_f32_pair_kernel(GemmArgs g1, Ge
 // overlap each other's k-loops and the step pays one launch instead of three or four.  Blocks are dealt to the problems in
 // order (largest first); every problem is a TN product with 16-byte aligned operands and more than 32 columns.
 constexpr int MULTI_MAX = 4;
-struct MultiArgs { GemmArgs g[MULTI_MAX]; int nb[MULTI_MAX]; int gx[MULTI_MAX]; int n; };
+#include "colsum_body.h"
+// cs_blocks > 0: the launch also carries the step's column sums (wfd_colsum_multi_rmsprop's work: bias / head gradients with
+// their RMSprop step, loss scalars, the step's bookkeeping) in its FIRST cs_blocks workgroups, one 32-column block each:
+// they read what the products read and write other memory, and they are done before the last tiles have started.
+struct MultiArgs { GemmArgs g[MULTI_MAX]; int nb[MULTI_MAX]; int gx[MULTI_MAX]; int n;
+                   const long long* cs_desc; int cs_nseg, cs_blocks; ColsumOpt cs; };
 
 __global__ __launch_bounds__(NTHREADS) void gemm_f32_rms_multi_kernel(MultiArgs a) {
     __shared__ __attribute__((aligned(16))) float lds[4 * TILE_F];
-    int id = blockIdx.x, k = 0;
+    if ((int)blockIdx.x < a.cs_blocks) {                                 // uniform over the workgroup
+        colsum_multi_body256<true>(a.cs_desc, a.cs_nseg, a.cs, blockIdx.x, lds);
+        return;
+    }
+    int id = blockIdx.x - a.cs_blocks, k = 0;
     while (k < a.n - 1 && id >= a.nb[k]) { id -= a.nb[k]; ++k; }       // uniform over the workgroup
     gemm_f32_body<false, false, 4, 4, false, false, 2>(a.g[k], lds, id % a.gx[k], id / a.gx[k], 0);
 }
@@ -888,9 +897,30 @@ int wfd_gemm_f32_rmsprop(int layout, const float* A, int lda, const float* B, in
 // desc (HOST memory): n problems x 10 64-bit words [A, lda, B, ldb, M, N, K, P, ldp, SQ], each as wfd_gemm_f32_rmsprop with
 // layout 2 (TN).  WFD_ERR_ARG when a problem does not fit the fast form (unaligned operands, N <= 32, n > 4): the caller
 // then launches them one by one.
+static int rms_multi_launch(const long long* desc, int n, float lr, float alpha, float eps, const long long* cs_desc,
+                            int cs_nseg, int cs_blocks, const ColsumOpt& cs, void* stream);
+
 int wfd_gemm_f32_rmsprop_multi(const long long* desc, int n, float lr, float alpha, float eps, void* stream) {
+    return rms_multi_launch(desc, n, lr, alpha, eps, nullptr, 0, 0, ColsumOpt{}, stream);
+}
+
+// the same launch also carrying wfd_colsum_multi_rmsprop(cs_desc, cs_nseg, cs_blocks, gbase, pbase, sqbase, numel, lr, alpha,
+// eps, state, inc0, inc1): the whole end of a critic step (weight gradients, bias / head gradients, every RMSprop update, loss
+// scalars, bookkeeping) in one launch.  The column sums must not read what the products write (the parameter matrices).
+int wfd_gemm_f32_rmsprop_multi_colsum(const long long* desc, int n, float lr, float alpha, float eps, const long long* cs_desc,
+                                      int cs_nseg, int cs_blocks, const float* gbase, float* pbase, float* sqbase, long numel,
+                                      unsigned long long* state, unsigned long long inc0, unsigned long long inc1,
+                                      void* stream) {
+    if (!cs_desc || cs_nseg <= 0 || cs_blocks <= 0 || !gbase || !pbase || !sqbase || numel <= 0) return WFD_ERR_ARG;
+    const ColsumOpt cs{gbase, pbase, sqbase, numel, lr, alpha, eps, state, inc0, inc1};
+    return rms_multi_launch(desc, n, lr, alpha, eps, cs_desc, cs_nseg, cs_blocks, cs, stream);
+}
+
+static int rms_multi_launch(const long long* desc, int n, float lr, float alpha, float eps, const long long* cs_desc,
+                            int cs_nseg, int cs_blocks, const ColsumOpt& cs, void* stream) {
     if (!desc || n < 1 || n > MULTI_MAX || g_gemm_mode != 0) return WFD_ERR_ARG;
     MultiArgs a{};
+    a.cs_desc = cs_desc; a.cs_nseg = cs_nseg; a.cs_blocks = cs_blocks; a.cs = cs;
     a.n = n;
     long total = 0;
     for (int k = 0; k < n; ++k) {
@@ -915,7 +945,7 @@ int wfd_gemm_f32_rmsprop_multi(const long long* desc, int n, float lr, float alp
         a.g[k].D = reinterpret_cast<const float*>(g_multi_stamps + (long)k * g_multi_nslots * 4); a.g[k].ldd = g_multi_nslots;
     }
 #endif
-    hipLaunchKernelGGL(gemm_f32_rms_multi_kernel, dim3((unsigned)total), dim3(NTHREADS), 0, (hipStream_t)stream, a);
+    hipLaunchKernelGGL(gemm_f32_rms_multi_kernel, dim3((unsigned)(total + cs_blocks)), dim3(NTHREADS), 0, (hipStream_t)stream, a);
     WFD_CHECK_LAUNCH();
     return WFD_OK;
 }

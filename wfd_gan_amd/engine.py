@@ -528,6 +528,7 @@ class TrainEngine:
         # product over the stacked [penalty ; standard] rows) runs beside it on the side lane as soon as its
         # operands exist
         Dp = D.p
+        d_problems = None
         if self.fuse_d:
             # single GPU: the whole t-chain first (it reads W_1..W_3), then the three weight gradients, each consumed by RMSprop
             # in its own store, as ONE launch
@@ -535,10 +536,13 @@ class TrainEngine:
             p.gemm_mul(NT, b["XC"], self.ldx, Dp["model.0.weight"], ld1, M, 2048, S, b["D1"], 2048, DM_MUL, None, b["T1H1"][:M], 2048)
             p.gemm_mul(NT, b["T1H1"][:M], 2048, Dp["model.3.weight"], 2048, M, 1024, 2048, b["D2"], 1024, DM_MUL, None, b["T2H2"][:M], 1024)
             p.gemm_mul(NT, b["T2H2"][:M], 1024, Dp["model.6.weight"], 1024, M, 512, 1024, b["D3"], 512, DM_MUL, None, b["T3"], 512)
-            p.gemm_rms_multi([
+            d_problems = [
                 (b["DL1"], 2048, b["XC"], self.ldx, 2048, S + C, 2 * M, Dp["model.0.weight"], ld1, D.s["model.0.weight"]),
                 (b["DL2"], 1024, b["T1H1"], 2048, 1024, 2048, 2 * M, Dp["model.3.weight"], 2048, D.s["model.3.weight"]),
-                (b["DL3"], 512, b["T2H2"], 1024, 512, 1024, 2 * M, Dp["model.6.weight"], 1024, D.s["model.6.weight"])], self.lr)
+                (b["DL3"], 512, b["T2H2"], 1024, 512, 1024, 2 * M, Dp["model.6.weight"], 1024, D.s["model.6.weight"])]
+            if os.environ.get("WFD_D_END_MERGE", "1") == "0":             # (the switch: same-session A/B)
+                p.gemm_rms_multi(d_problems, self.lr)
+                d_problems = None
         elif self.pair:
             # each layer's weight gradient (one TN product over the stacked [penalty ; standard] rows) shares a launch
             # with the t-chain product that follows it: neither reads what the other writes
@@ -558,7 +562,7 @@ class TrainEngine:
         st_arg = (st if fast else 0, self._rng_inc() if fast else 0, (self.cursor_step if own_cursor else 0) if fast else 0)
         # single GPU with the matrices updated in their gradients' stores: every remaining critic parameter (biases, head) has
         # its gradient produced by THIS launch, which then applies their RMSprop step too and ends the D-step
-        self._colsum_multi(p, "d_small", bias_segs + [
+        d_segs = bias_segs + [
             (b["T3"], 512, None, b["H3"], 512, b["DV"], M, 512, D.g["model.9.weight"]),
             (b["DV"], 1, None, None, 0, None, M, 1, D.g["model.9.bias"]),
             # loss scalars of :215-227 as weighted column sums of the per-row critic scores / penalties:
@@ -567,7 +571,16 @@ class TrainEngine:
             (b["PEN"], 1, b["INVB"], None, 0, None, M, 1, b["dstats"][1:2]),
             (b["V"], 1, b["NDV"], None, 0, None, M, 1, b["dstats"][2:3], b["dacc"][1:2]),
             (b["V"], 1, b["RSELR"], None, 0, None, M, 1, b["dstats"][3:4]),
-            (b["V"], 1, b["RSELF"], None, 0, None, M, 1, b["dstats"][4:5])], opt=(D, st_arg) if self.fuse_d else None)
+            (b["V"], 1, b["RSELF"], None, 0, None, M, 1, b["dstats"][4:5])]
+        if self.fuse_d and d_problems is not None:
+            # ... and those column sums ride in the first workgroups of the weight-gradient launch: the end of the D-step
+            # is ONE launch (they read the chain's activations and row scalars, never the parameter matrices)
+            desc, blk = self._colsum_desc(p, d_segs)
+            if not p.gemm_rms_multi(d_problems, self.lr, colsum=(ptr(desc), len(d_segs), blk, ptr(D.grad), ptr(D.flat), ptr(D.sq),
+                                                                  D.numel) + st_arg):
+                self._colsum_multi(p, "d_small", d_segs, opt=(D, st_arg))
+            return p
+        self._colsum_multi(p, "d_small", d_segs, opt=(D, st_arg) if self.fuse_d else None)
         if self.fuse_d:
             return p
         if self.overlap:
@@ -613,10 +626,8 @@ class TrainEngine:
         s = p.gemm(NT, b["T2H2"][:M], 1024, Dp["model.6.weight"], 1024, M, 512, 1024)
         p.mul(s, b["D3"], 512, DM_MUL, None, None, b["T3"], None, 512)
 
-    def _colsum_multi(self, p: Plan, name: str, segs, opt=None):
-        """segs: (X, ldx, rowscale, X2, ldx2, rowscale2, M, N, out) -> one launch of wfd_colsum_multi.
-        opt = (FlatParams, (state, inc0, inc1)): outputs inside that network's gradient buffer also take their RMSprop
-        step in the launch (wfd_colsum_multi_rmsprop), which then does the step's bookkeeping."""
+    def _colsum_desc(self, p: Plan, segs):
+        """Device descriptor of wfd_colsum_multi's segments (11 words each) and the launch's number of 32-column blocks."""
         rows, blk = [], 0
         for sg in segs:
             X, ldx, rs, X2, ldx2, rs2, M, N, out = sg[:9]
@@ -625,6 +636,14 @@ class TrainEngine:
             blk += (N + 31) // 32
         desc = torch.tensor(rows, dtype=torch.int64, device=self.dev)
         p.keep.append(desc)          # owned by the plan: a later rebuild of a D plan must not free what this one points at
+        return desc, blk
+
+    def _colsum_multi(self, p: Plan, name: str, segs, opt=None):
+        """segs: (X, ldx, rowscale, X2, ldx2, rowscale2, M, N, out) -> one launch of wfd_colsum_multi.
+        opt = (FlatParams, (state, inc0, inc1)): outputs inside that network's gradient buffer also take their RMSprop
+        step in the launch (wfd_colsum_multi_rmsprop), which then does the step's bookkeeping."""
+        desc, blk = self._colsum_desc(p, segs)
+        rows = segs
         if opt is None:
             p.add(self.L.colsum_multi, ptr(desc), len(rows), blk)
         else:
