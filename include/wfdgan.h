@@ -215,6 +215,15 @@ int wfd_gemm_f32_rmsprop_multi_colsum(const long long* desc, int n, float lr, fl
                                       int cs_nseg, int cs_blocks, const float* gbase, float* pbase, float* sqbase, long numel,
                                       unsigned long long* state, unsigned long long inc0, unsigned long long inc1,
                                       void* stream);
+/* ... and also the other two parts of wfd_g_end (RMSprop on `ranges`; the BatchNorm running statistics, meanA = NULL leaves
+ * them out): the whole end of a generator step (loss.backward()'s weight / bias gradients with optimizer_G.step(),
+ * src/mlp_df_wgan_train.py:273-275, and the second forward's running-statistics update, :240) as ONE launch */
+int wfd_gemm_f32_rmsprop_multi_end(const long long* desc, int n, float lr, float alpha, float eps, const long long* cs_desc,
+                                   int cs_nseg, int cs_blocks, const float* gbase, float* pbase, float* sqbase, long numel,
+                                   const long* ranges, int nranges, unsigned long long* state, unsigned long long inc0,
+                                   unsigned long long inc1, const float* meanA, const float* m2A, int NA, float* rmeanA,
+                                   float* rvarA, const float* meanB, const float* m2B, int NB, float* rmeanB, float* rvarB,
+                                   float count, float momentum, int groups, int nupd_last, void* stream);
 
 /* nn.BatchNorm1d(n, eps=0.8) training forward (src/model.py:23), in two halves so that data-parallel ranks can
  * combine (mean, M2) in between: stats writes Z = sumP + bias and the per-column mean / sum of squared deviations;

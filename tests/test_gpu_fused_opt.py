@@ -206,19 +206,19 @@ def test_grouped_observer_ahead_is_bit_identical(graphs):
         assert torch.equal(a, b), f"tensor {k} differs between the two schedules"
 
 
-@pytest.mark.parametrize("switch,part,fewer", [("WFD_HEAD_MERGE", "head", 3), ("WFD_G_END_MERGE", "gstep", 2),
+@pytest.mark.parametrize("switch,part,fewer", [("WFD_HEAD_MERGE", "head", 3), ("WFD_G_END_MERGE", "gstep", 3),
                                                ("WFD_D_END_MERGE", "rest", 1)])
 @pytest.mark.parametrize("graphs", [False, True])
 def test_grouped_head_merged_launches_are_bit_identical(graphs, switch, part, fewer, monkeypatch):
     """Small independent launches of a group sharing one launch, against one launch each.  WFD_HEAD_MERGE: the head of a group with its three independent draws (dropout masks of every pass, gathered batches + one-hot
     columns, z) in one launch (wfd_group_inputs) and the state advance folded into the last launch
     (wfd_ep_sigmoid_lenmask_slots_adv): 3 launches fewer.  WFD_G_END_MERGE: the end of the fused G-step (first layer's bias
-    gradient and its RMSprop step, the other vectors' steps, the BatchNorm running statistics) as wfd_g_end: 2 fewer.
+    gradient and its RMSprop step, the other vectors' steps, the BatchNorm running statistics) in the first workgroups of the weight-gradient launch (wfd_gemm_f32_rmsprop_multi_end): 3 fewer.
     WFD_D_END_MERGE: the column sums that end a fused D-step (bias / head gradients with their steps, loss scalars,
     bookkeeping) in the first workgroups of the weight-gradient launch (wfd_gemm_f32_rmsprop_multi_colsum): 1 fewer per D-step.
     Every state tensor bit-identical after three groups (the second and third group see the advanced counter / cursor)."""
     from wfd_gan_amd.engine import GroupedTrainer, TrainEngine
-    S, C, Z, B = 101, 6, 24, 16
+    S, C, Z, B = 101, 6, 42, 16          # Z + C > 32: the generator's first layer takes the multi-product launch too
     X, y = O.synth_dataset(C, 30, S - 1, 10, 13, 122, seed=1)
     dmin, dmax = X.min(0), X.max(0)
     scale, min_ = O.scaler_params(dmin, dmax)

@@ -83,3 +83,41 @@ __device__ __forceinline__ void colsum_multi_body256(const long long* __restrict
         }
     }
 }
+
+// ---- the other small bodies a step's last launch may carry (wfd_g_end, wfd_gemm_f32_rmsprop_multi_end) -------------------
+// RMSprop on up to 8 element ranges [beg, end) of the flat buffers; i = element index over the concatenated ranges
+struct RmsRanges { long beg[8], end[8]; int n; };
+__device__ __forceinline__ void rmsprop_ranges_body(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ sq,
+                                                    const RmsRanges& r, float lr, float alpha, float eps, long i) {
+    for (int k = 0; k < r.n; ++k) {
+        const long len = r.end[k] - r.beg[k];
+        if (i < len) {
+            const long j = r.beg[k] + i;
+            float pj = p[j], sj = sq[j];
+            rmsprop_update(pj, sj, g[j], lr, alpha, eps);
+            sq[j] = sj;
+            p[j] = pj;
+            return;
+        }
+        i -= len;
+    }
+}
+
+// running statistics of one BatchNorm layer over `groups` stacked batches (see bn_running_update_layers_kernel)
+struct BnLayer { const float* mean; const float* m2; float* rmean; float* rvar; int N; };
+__device__ __forceinline__ void bn_running_layer_body(const BnLayer& l, int n, float count, float momentum, int groups,
+                                                      int nupd_last) {
+    if (n >= l.N) return;
+    float rm = l.rmean[n], rv = l.rvar[n];
+    for (int g = 0; g < groups; ++g) {
+        const float mu = l.mean[(long)g * l.N + n], uv = l.m2[(long)g * l.N + n] / (count - 1.f);
+        const int nu = g == groups - 1 ? nupd_last : 1;
+        for (int u = 0; u < nu; ++u) {
+            rm = (1.f - momentum) * rm + momentum * mu;
+            rv = (1.f - momentum) * rv + momentum * uv;
+        }
+    }
+    l.rmean[n] = rm;
+    l.rvar[n] = rv;
+}
+struct BnRun { BnLayer a, b; float count, momentum; int groups, nupd_last, bn_blocks; };

@@ -377,22 +377,6 @@ __global__ void rmsprop_kernel(float* __restrict__ p, const float* __restrict__ 
 
 // The same update on up to 8 element ranges [beg, end) of the flat buffers: the vectors (biases, BatchNorm affine, the
 // critic's head) of a network whose weight matrices were updated in their gradient's store (wfd_gemm_f32_rmsprop).
-struct RmsRanges { long beg[8], end[8]; int n; };
-__device__ __forceinline__ void rmsprop_ranges_body(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ sq,
-                                                    const RmsRanges& r, float lr, float alpha, float eps, long i) {
-    for (int k = 0; k < r.n; ++k) {
-        const long len = r.end[k] - r.beg[k];
-        if (i < len) {
-            const long j = r.beg[k] + i;
-            float pj = p[j], sj = sq[j];
-            rmsprop_update(pj, sj, g[j], lr, alpha, eps);
-            sq[j] = sj;
-            p[j] = pj;
-            return;
-        }
-        i -= len;
-    }
-}
 __global__ void rmsprop_ranges_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ sq, RmsRanges r,
                                       float lr, float alpha, float eps, unsigned long long* __restrict__ state,
                                       unsigned long long inc0, unsigned long long inc1) {
@@ -607,22 +591,6 @@ __global__ void bn_running_update_kernel(const float* __restrict__ mean, const f
 // Both BatchNorm layers of the generator in one launch, for a whole group of stacked forwards: blockIdx.y selects the
 // layer; its `groups` batches are applied in order, the last one `nupd_last` times (the G-step's second forward of the same
 // batch, src/mlp_df_wgan_train.py:240).  Element for element the operations of bn_running_update_kernel applied batch by batch.
-struct BnLayer { const float* mean; const float* m2; float* rmean; float* rvar; int N; };
-__device__ __forceinline__ void bn_running_layer_body(const BnLayer& l, int n, float count, float momentum, int groups,
-                                                      int nupd_last) {
-    if (n >= l.N) return;
-    float rm = l.rmean[n], rv = l.rvar[n];
-    for (int g = 0; g < groups; ++g) {
-        const float mu = l.mean[(long)g * l.N + n], uv = l.m2[(long)g * l.N + n] / (count - 1.f);
-        const int nu = g == groups - 1 ? nupd_last : 1;
-        for (int u = 0; u < nu; ++u) {
-            rm = (1.f - momentum) * rm + momentum * mu;
-            rv = (1.f - momentum) * rv + momentum * uv;
-        }
-    }
-    l.rmean[n] = rm;
-    l.rvar[n] = rv;
-}
 __global__ void bn_running_update_layers_kernel(BnLayer a, BnLayer b, float count, float momentum, int groups, int nupd_last) {
     bn_running_layer_body(blockIdx.y ? b : a, blockIdx.x * blockDim.x + threadIdx.x, count, momentum, groups, nupd_last);
 }
@@ -632,7 +600,6 @@ __global__ void bn_running_update_layers_kernel(BnLayer a, BnLayer b, float coun
 //   the next rr_blocks               RMSprop on the other vector ranges of the flat buffers                   = rmsprop_ranges
 //   the last 2 * bn_blocks           running statistics of the two BatchNorm layers, all stacked batches      = bn_running_update_layers
 // The three parts touch disjoint memory and each is the body of the kernel it replaces.  Blocks are (CT, RG) threads.
-struct BnRun { BnLayer a, b; float count, momentum; int groups, nupd_last, bn_blocks; };
 __global__ void g_end_kernel(const long long* __restrict__ desc, int nseg, int cs_blocks, ColsumOpt o, RmsRanges r,
                              int rr_blocks, BnRun bn) {
     __shared__ float red[RG][CT];

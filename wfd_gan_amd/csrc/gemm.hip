@@ -395,8 +395,11 @@ constexpr int MULTI_MAX = 4;
 // cs_blocks > 0: the launch also carries the step's column sums (wfd_colsum_multi_rmsprop's work: bias / head gradients with
 // their RMSprop step, loss scalars, the step's bookkeeping) in its FIRST cs_blocks workgroups, one 32-column block each:
 // they read what the products read and write other memory, and they are done before the last tiles have started.
+// rr_blocks / bn.bn_blocks > 0: likewise the RMSprop of the other vector ranges and the BatchNorm running statistics (the
+// rest of wfd_g_end's work), in the workgroups behind the column sums.
 struct MultiArgs { GemmArgs g[MULTI_MAX]; int nb[MULTI_MAX]; int gx[MULTI_MAX]; int n;
-                   const long long* cs_desc; int cs_nseg, cs_blocks; ColsumOpt cs; };
+                   const long long* cs_desc; int cs_nseg, cs_blocks; ColsumOpt cs;
+                   RmsRanges rr; int rr_blocks; BnRun bn; };
 
 __global__ __launch_bounds__(NTHREADS) void gemm_f32_rms_multi_kernel(MultiArgs a) {
     __shared__ __attribute__((aligned(16))) float lds[4 * TILE_F];
@@ -405,6 +408,18 @@ __global__ __launch_bounds__(NTHREADS) void gemm_f32_rms_multi_kernel(MultiArgs 
         return;
     }
     int id = blockIdx.x - a.cs_blocks, k = 0;
+    if (id < a.rr_blocks) {
+        rmsprop_ranges_body(a.cs.pbase, a.cs.gbase, a.cs.sqbase, a.rr, a.cs.lr, a.cs.alpha, a.cs.eps,
+                            (long)id * NTHREADS + threadIdx.x);
+        return;
+    }
+    id -= a.rr_blocks;
+    if (id < 2 * a.bn.bn_blocks) {
+        bn_running_layer_body(id / a.bn.bn_blocks ? a.bn.b : a.bn.a, (id % a.bn.bn_blocks) * NTHREADS + threadIdx.x, a.bn.count,
+                              a.bn.momentum, a.bn.groups, a.bn.nupd_last);
+        return;
+    }
+    id -= 2 * a.bn.bn_blocks;
     while (k < a.n - 1 && id >= a.nb[k]) { id -= a.nb[k]; ++k; }       // uniform over the workgroup
     gemm_f32_body<false, false, 4, 4, false, false, 2>(a.g[k], lds, id % a.gx[k], id / a.gx[k], 0);
 }
@@ -898,7 +913,8 @@ int wfd_gemm_f32_rmsprop(int layout, const float* A, int lda, const float* B, in
 // layout 2 (TN).  WFD_ERR_ARG when a problem does not fit the fast form (unaligned operands, N <= 32, n > 4): the caller
 // then launches them one by one.
 static int rms_multi_launch(const long long* desc, int n, float lr, float alpha, float eps, const long long* cs_desc,
-                            int cs_nseg, int cs_blocks, const ColsumOpt& cs, void* stream);
+                            int cs_nseg, int cs_blocks, const ColsumOpt& cs, void* stream, const RmsRanges* rr = nullptr,
+                            int rr_blocks = 0, const BnRun* bn = nullptr);
 
 int wfd_gemm_f32_rmsprop_multi(const long long* desc, int n, float lr, float alpha, float eps, void* stream) {
     return rms_multi_launch(desc, n, lr, alpha, eps, nullptr, 0, 0, ColsumOpt{}, stream);
@@ -916,11 +932,48 @@ int wfd_gemm_f32_rmsprop_multi_colsum(const long long* desc, int n, float lr, fl
     return rms_multi_launch(desc, n, lr, alpha, eps, cs_desc, cs_nseg, cs_blocks, cs, stream);
 }
 
+// ... and also wfd_g_end's other two parts (RMSprop on `ranges`, the BatchNorm running statistics; meanA = NULL leaves those
+// out): the whole end of a generator step as ONE launch.
+int wfd_gemm_f32_rmsprop_multi_end(const long long* desc, int n, float lr, float alpha, float eps, const long long* cs_desc,
+                                   int cs_nseg, int cs_blocks, const float* gbase, float* pbase, float* sqbase, long numel,
+                                   const long* ranges, int nranges, unsigned long long* state, unsigned long long inc0,
+                                   unsigned long long inc1, const float* meanA, const float* m2A, int NA, float* rmeanA,
+                                   float* rvarA, const float* meanB, const float* m2B, int NB, float* rmeanB, float* rvarB,
+                                   float count, float momentum, int groups, int nupd_last, void* stream) {
+    if (!cs_desc || cs_nseg <= 0 || cs_blocks <= 0 || !gbase || !pbase || !sqbase || numel <= 0) return WFD_ERR_ARG;
+    if (!ranges || nranges < 1 || nranges > 8) return WFD_ERR_ARG;
+    const ColsumOpt cs{gbase, pbase, sqbase, numel, lr, alpha, eps, state, inc0, inc1};
+    RmsRanges r{};
+    long total = 0;
+    for (int k = 0; k < nranges; ++k) {
+        r.beg[k] = ranges[2 * k]; r.end[k] = ranges[2 * k + 1];
+        if (r.beg[k] < 0 || r.end[k] < r.beg[k] || r.end[k] > numel) return WFD_ERR_ARG;
+        total += r.end[k] - r.beg[k];
+    }
+    r.n = nranges;
+    if (total <= 0) return WFD_ERR_ARG;
+    BnRun bn{};
+    if (meanA) {
+        if (!m2A || !rmeanA || !rvarA || !meanB || !m2B || !rmeanB || !rvarB || NA < 1 || NB < 1 || groups < 1 ||
+            nupd_last < 0 || count <= 1.f)
+            return WFD_ERR_ARG;
+        bn.a = BnLayer{meanA, m2A, rmeanA, rvarA, NA};
+        bn.b = BnLayer{meanB, m2B, rmeanB, rvarB, NB};
+        bn.count = count; bn.momentum = momentum; bn.groups = groups; bn.nupd_last = nupd_last;
+        bn.bn_blocks = cdiv(NA > NB ? NA : NB, NTHREADS);
+    }
+    return rms_multi_launch(desc, n, lr, alpha, eps, cs_desc, cs_nseg, cs_blocks, cs, stream, &r, cdiv(total, NTHREADS), &bn);
+}
+
 static int rms_multi_launch(const long long* desc, int n, float lr, float alpha, float eps, const long long* cs_desc,
-                            int cs_nseg, int cs_blocks, const ColsumOpt& cs, void* stream) {
+                            int cs_nseg, int cs_blocks, const ColsumOpt& cs, void* stream, const RmsRanges* rr, int rr_blocks,
+                            const BnRun* bn) {
     if (!desc || n < 1 || n > MULTI_MAX || g_gemm_mode != 0) return WFD_ERR_ARG;
     MultiArgs a{};
     a.cs_desc = cs_desc; a.cs_nseg = cs_nseg; a.cs_blocks = cs_blocks; a.cs = cs;
+    if (rr) { a.rr = *rr; a.rr_blocks = rr_blocks; }
+    if (bn) a.bn = *bn;
+    const int small_blocks = cs_blocks + a.rr_blocks + 2 * a.bn.bn_blocks;
     a.n = n;
     long total = 0;
     for (int k = 0; k < n; ++k) {
@@ -945,7 +998,7 @@ static int rms_multi_launch(const long long* desc, int n, float lr, float alpha,
         a.g[k].D = reinterpret_cast<const float*>(g_multi_stamps + (long)k * g_multi_nslots * 4); a.g[k].ldd = g_multi_nslots;
     }
 #endif
-    hipLaunchKernelGGL(gemm_f32_rms_multi_kernel, dim3((unsigned)(total + cs_blocks)), dim3(NTHREADS), 0, (hipStream_t)stream, a);
+    hipLaunchKernelGGL(gemm_f32_rms_multi_kernel, dim3((unsigned)(total + small_blocks)), dim3(NTHREADS), 0, (hipStream_t)stream, a);
     WFD_CHECK_LAUNCH();
     return WFD_OK;
 }

@@ -853,12 +853,15 @@ class TrainEngine:
             if not end_merge:
                 p.add(self.L.colsum, ptr(b["GDZ1"]), 512, B, 512, 0, ptr(G.g["model.0.bias"]), 0)
             # the activation-gradient chain is done (it read W_8, W_5, W_2): all four weight gradients, one launch
-            p.gemm_rms_multi([
+            g_problems = [
                 (b["GDZ4"], self.lds4, b["GH3"], 2048, S, 2048, B, Gp["model.8.weight"], 2048, G.s["model.8.weight"]),
                 (b["GDZ3"], 2048, b["GH2"], 1024, 2048, 1024, B, Gp["model.5.weight"], 1024, G.s["model.5.weight"]),
                 (b["GDZ2"], 1024, b["GH1"], 512, 1024, 512, B, Gp["model.2.weight"], 512, G.s["model.2.weight"]),
                 (b["GDZ1"], 512, b["ZIN"], self.ldz, 512, Z + C, B, Gp["model.0.weight"], G.ld["model.0.weight"],
-                 G.s["model.0.weight"])], self.lr)
+                 G.s["model.0.weight"])]
+            one = end_merge and os.environ.get("WFD_G_END_MERGE", "1") != "2"       # ("2": wfd_g_end as its own launch)
+            if not one:
+                p.gemm_rms_multi(g_problems, self.lr)
             if end_merge:
                 # first layer's bias gradient + its step, the other vectors' steps, the BN running statistics: one launch
                 desc = torch.tensor([[ptr(b["GDZ1"]), 512, 0, 0, 0, 0, B, 512, ptr(G.g["model.0.bias"]), 0, 0]],
@@ -867,8 +870,13 @@ class TrainEngine:
                 flat = [v for r in G.vector_ranges() if r[0] != b0 for v in r]
                 arr = (ctypes.c_long * len(flat))(*flat)
                 p.keep += [desc, arr]
-                p.add(self.L.g_end, ptr(desc), 1, 512 // 32, ptr(G.grad), ptr(G.flat), ptr(G.sq), G.numel, arr, len(flat) // 2,
-                      self.lr, 0.99, 1e-8, st if fast else 0, self._rng_inc() if fast else 0, 0, *bn_run)
+                st_arg = (st if fast else 0, self._rng_inc() if fast else 0, 0)
+                # ... riding in the first workgroups of the weight-gradient launch: the end of the G-step is ONE launch
+                if not (one and p.gemm_rms_multi(g_problems, self.lr, colsum=(ptr(desc), 1, 512 // 32, ptr(G.grad), ptr(G.flat),
+                                                                               ptr(G.sq), G.numel) + st_arg
+                                                 + (arr, len(flat) // 2) + bn_run)):
+                    p.add(self.L.g_end, ptr(desc), 1, 512 // 32, ptr(G.grad), ptr(G.flat), ptr(G.sq), G.numel, arr, len(flat) // 2,
+                          self.lr, 0.99, 1e-8, *st_arg, *bn_run)
             else:
                 self._optimizer(p, G, True, st if fast else 0, self._rng_inc() if fast else 0, 0)
             return p

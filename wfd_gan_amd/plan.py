@@ -306,9 +306,14 @@ class Plan:
                 words += [ptr(A), lda, ptr(B), ldb, M, N, K, ptr(P), ldp, ptr(SQ)]
             arr = (ctypes.c_longlong * len(words))(*words)
             self.keep.append(arr)
-            desc, nseg, blk, gbase, pbase, sqbase, numel, state, inc0, inc1 = colsum
-            self.add(self.L.gemm_f32_rmsprop_multi_colsum, arr, len(problems), lr, alpha, eps, desc, nseg, blk, gbase, pbase,
-                     sqbase, numel, state, inc0, inc1)
+            if len(colsum) == 10:
+                desc, nseg, blk, gbase, pbase, sqbase, numel, state, inc0, inc1 = colsum
+                self.add(self.L.gemm_f32_rmsprop_multi_colsum, arr, len(problems), lr, alpha, eps, desc, nseg, blk, gbase, pbase,
+                         sqbase, numel, state, inc0, inc1)
+            else:       # + (ranges, nranges) + the 14 arguments of wfd_bn_running_update_layers: wfd_g_end's work as well
+                desc, nseg, blk, gbase, pbase, sqbase, numel, state, inc0, inc1, ranges, nranges = colsum[:12]
+                self.add(self.L.gemm_f32_rmsprop_multi_end, arr, len(problems), lr, alpha, eps, desc, nseg, blk, gbase, pbase,
+                         sqbase, numel, ranges, nranges, state, inc0, inc1, *colsum[12:])
             return True
         for a in range(0, len(problems), 4):
             chunk = problems[a:a + 4]
