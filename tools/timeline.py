@@ -4,7 +4,7 @@
     rocprofv3 --kernel-trace --output-format csv -d gpurun_out/tl -- python bench.py --steps 30 --warmup 6 --no-cpu-baseline --no-sampling
     python tools/timeline.py gpurun_out/tl [out.txt]
 
-Takes the last complete group (from one gather_batch_slots launch to the next) and prints, per launch: start offset,
+Takes the last complete group (from one group_inputs / gather_batch_slots launch to the next) and prints, per launch: start offset,
 duration, gap to the previous launch's end, grid, short name; then the sums per kernel family.
 """
 import csv, glob, re, sys
@@ -21,7 +21,7 @@ for f in glob.glob(sys.argv[1] + "/**/*kernel_trace.csv", recursive=True):
                      "x".join(r.get(k, "?") for k in ("Grid_Size_X", "Grid_Size_Y", "Grid_Size_Z")),
                      r.get("Workgroup_Size_X", "?")))
 rows.sort()
-marks = [i for i, r in enumerate(rows) if r[2].startswith("gather_batch")]
+marks = [i for i, r in enumerate(rows) if r[2].startswith("gather_batch") or r[2].startswith("group_inputs")]
 if len(marks) < 3:
     sys.exit("no complete group in the trace")
 a, b = marks[-3], marks[-2]

@@ -36,6 +36,10 @@ extern "C" int wfd_get_gemm_mode(void);
 
 namespace {
 
+#ifndef WFD_WK_PREFETCH_EPI
+#define WFD_WK_PREFETCH_EPI 1
+#endif
+constexpr bool PREFETCH_EPI = WFD_WK_PREFETCH_EPI != 0;
 constexpr int KC = 32;         // k per chunk (one 128-byte row segment)
 constexpr int LDK = KC + 4;    // row stride of a k-contiguous tile: 36 floats, conflict-free ds_read_b128 / ds_write_b128
 
@@ -253,6 +257,35 @@ __device__ __forceinline__ void gemm_wk_body(const WkArgs& g, float* __restrict_
         }
     };
 
+    // ---- what the epilogue will read for this thread's float4 group of the tile (chain factor D, dropout mask, shift /
+    //      scale, row scale) is requested HERE, ahead of the k-loop: behind the fold barrier each of these loads is a
+    //      dependent round trip in front of the store, on the critical path of every launch of the batch-64 step
+    constexpr int Q = TN / 4, NQ = TM * Q;           // float4 groups of the tile
+    float pd[4] = {0.f, 0.f, 0.f, 0.f}, pm[4] = {0.f, 0.f, 0.f, 0.f}, psh[4] = {0.f, 0.f, 0.f, 0.f}, psc[4] = {1.f, 1.f, 1.f, 1.f};
+    float prs = 0.f;
+    if (PREFETCH_EPI && (int)threadIdx.x < NQ) {
+        const int prow = m0 + (int)threadIdx.x / Q, pcol = n0 + 4 * ((int)threadIdx.x % Q);
+        if (prow < g.M && pcol < g.N) {
+            const int pnv = min(4, g.N - pcol);
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                if (k < pnv) {
+                    if (g.epi == 1) {
+                        if (g.shift) psh[k] = g.shift[pcol + k];
+                        if (g.scale) psc[k] = g.scale[pcol + k];
+                    } else if (g.epi == 2) {
+                        if (g.dmode) pd[k] = g.D[(long)prow * g.ldd + pcol + k];
+                        if (g.scale) psc[k] = g.scale[pcol + k];
+                    } else if (g.epi == 3) {
+                        psh[k] = g.shift[pcol + k];
+                        pm[k] = g.mask[(long)prow * g.ldmask + pcol + k];
+                    }
+                }
+            }
+            if (g.epi == 2 && g.out2) prs = g.rowscale[prow];
+        }
+    }
+
     // main loop over the wave's interior chunks only (the ragged last chunk of K, if this wave owns it, runs after the
     // loop: with its element-wise loads inside the loop body the compiler waits for every load right after issuing it)
     const int c1f = min(c1, g.K / KC);
@@ -288,8 +321,8 @@ __device__ __forceinline__ void gemm_wk_body(const WkArgs& g, float* __restrict_
 #pragma unroll
             for (int r = 0; r < 4; ++r) wsm[(16 * a + 4 * g4 + r) * TNP + 16 * b + c16] = acc[a][b][r];
     __syncthreads();
-    constexpr int Q = TN / 4, NQ = TM * Q;           // float4 groups of the tile
     for (int q = threadIdx.x; q < NQ; q += NW * 64) {
+        const bool first = PREFETCH_EPI && q == (int)threadIdx.x;       // this group's epilogue operands are in registers
         const int r = q / Q, cq = q % Q;
         const int row = m0 + r, col = n0 + 4 * cq;
         if (row >= g.M || col >= g.N) continue;
@@ -305,8 +338,8 @@ __device__ __forceinline__ void gemm_wk_body(const WkArgs& g, float* __restrict_
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
                 if (k < nv) {
-                    const float sh = g.shift ? g.shift[col + k] : 0.f;
-                    float x = g.scale ? __fmaf_rn(vv[k], g.scale[col + k], sh) : vv[k] + sh;
+                    const float sh = first ? psh[k] : (g.shift ? g.shift[col + k] : 0.f);
+                    float x = g.scale ? __fmaf_rn(vv[k], first ? psc[k] : g.scale[col + k], sh) : vv[k] + sh;
                     if (g.act == 1) x = fmaxf(x, 0.f);
                     else if (g.act == 2) x = x > 0.f ? x : elu_expm1(x);
                     else if (g.act == 3) x = 1.0f / (1.0f + expf(-x));
@@ -314,18 +347,18 @@ __device__ __forceinline__ void gemm_wk_body(const WkArgs& g, float* __restrict_
                 }
             }
         } else if (g.epi == 2) {
-            const float rs = g.out2 ? g.rowscale[row] : 0.f;
+            const float rs = first ? prs : (g.out2 ? g.rowscale[row] : 0.f);
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
                 if (k < nv) {
                     float x = vv[k];
                     if (g.dmode) {
-                        const float d = g.D[(long)row * g.ldd + col + k];
+                        const float d = first ? pd[k] : g.D[(long)row * g.ldd + col + k];
                         if (g.dmode == 1) x *= d;
                         else if (g.dmode == 2) x = d > 0.f ? x : 0.f;
                         else x = d > 0.f ? x : x * (d + 1.f);
                     }
-                    if (g.scale) x *= g.scale[col + k];
+                    if (g.scale) x *= first ? psc[k] : g.scale[col + k];
                     vv[k] = x;
                     v2[k] = x * rs;
                 }
@@ -334,8 +367,8 @@ __device__ __forceinline__ void gemm_wk_body(const WkArgs& g, float* __restrict_
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
                 if (k < nv) {
-                    const float zz = vv[k] + g.shift[col + k];
-                    const float mk = g.mask[(long)row * g.ldmask + col + k];
+                    const float zz = vv[k] + (first ? psh[k] : g.shift[col + k]);
+                    const float mk = first ? pm[k] : g.mask[(long)row * g.ldmask + col + k];
                     const float lr = zz > 0.f ? zz : zz * g.slope;
                     vv[k] = lr * mk;
                     v2[k] = zz > 0.f ? mk : mk * g.slope;
