@@ -494,6 +494,14 @@ __global__ __launch_bounds__(NTHREADS) void conv8_c32_kernel(GemmArgs g, int cpw
         // epi 2 (the input-gradient conv: out = acc * f(D)): the D tile is requested before the MFMA block instead of
         // behind it (-8 us per group of the B=64 step: the 16 dependent loads per lane no longer sit in front of the stores)
         float dv[16];
+        // epi 1 (forward conv: out = act(acc * scale[n] + shift[n])): the column's scale / shift likewise
+        const bool pf1 = EPI && g.epi == 1;
+        float psc = 1.f, psh = 0.f;
+        if (pf1) {
+            const int pcol = min(n0 + i, g.N - 1);
+            if (g.scale) psc = g.scale[pcol];
+            if (g.shift) psh = g.shift[pcol];
+        }
         const bool pfd = EPI && g.epi == 2 && g.dmode;
         if (pfd) {
             const int pcol = min(n0 + i, g.N - 1);
@@ -531,6 +539,12 @@ __global__ __launch_bounds__(NTHREADS) void conv8_c32_kernel(GemmArgs g, int cpw
                             else if (g.dmode == 2) v = d > 0.f ? v : 0.f;
                             else v = d > 0.f ? v : v * (d + 1.f);
                             if (g.scale) v *= g.scale[col];
+                            g.P[(long)row * g.ldp + col] = v;
+                        } else if (pf1) {
+                            float v = g.scale ? __fmaf_rn(acc[r], psc, psh) : acc[r] + psh;          // = epi_apply, epi 1
+                            if (g.act == 1) v = fmaxf(v, 0.f);
+                            else if (g.act == 2) v = v > 0.f ? v : elu_expm1(v);
+                            else if (g.act == 3) v = 1.0f / (1.0f + expf(-v));
                             g.P[(long)row * g.ldp + col] = v;
                         } else {
                             epi_store(g, g.P, acc[r], row, col);
