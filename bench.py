@@ -77,13 +77,9 @@ def run_steps(eng, start, n):
     """n iterations from iteration index `start`; whole groups of n_critic iterations go out as one graph replay
     where the engine offers it (re-permutes by itself at epoch ends)."""
     i, end = start, start + n
-    if hasattr(eng, "run_group"):               # GroupedTrainer: whole groups of n_critic iterations (D D D G)
-        nc = eng.n
-        for _ in range(n // nc):
-            eng.run_group()
-        for k in range(n % nc):                 # a K that is no multiple of n_critic: the rest on the plain engine
-            eng.base.iteration(start + (n // nc) * nc + k)
-        return
+    if hasattr(eng, "run_iterations"):          # GroupedTrainer: whole groups of n_critic iterations (D D D G) as one graph;
+        eng.run_iterations(n)                   # a K that is no multiple of n_critic stops inside a group and the next
+        return                                  # block continues there (the group's per-iteration graphs)
     group = getattr(eng, "iteration_group", None)
     nc = getattr(eng, "n_critic", 3)
     while i < end:
@@ -264,8 +260,8 @@ def main():
     if grouped:             # the generator forwards of the n_critic iterations sharing generator parameters run stacked
         from wfd_gan_amd.engine import GroupedTrainer
         drv = GroupedTrainer(eng, graphs=not args.no_graph, observer_ahead=bool(args.observer_ahead))
-        if not args.no_graph and args.steps % eng.n_critic:
-            eng.capture_graphs()
+        if (args.steps % eng.n_critic or args.warmup % eng.n_critic) and not args.observer_ahead:
+            drv._build_parts()
     elif pipelined:         # generator forward of iteration i+1 on a second stream beside iteration i's critic update
         from wfd_gan_amd.engine import PipelinedTrainer
         drv = PipelinedTrainer(eng, graphs=not args.no_graph)
@@ -283,10 +279,10 @@ def main():
     # The timed block is EXACTLY --steps iterations between barrier + synchronize on both sides, max over ranks.  It is
     # repeated --repeats times back to back (training simply continues) and the MEDIAN block time is reported, so that a
     # short block (the driver's --steps 20 is 7 ms) says the same as a long one; every block's time is in `block_ms`.
-    # A --steps that is no multiple of n_critic ends every block with 1-2 single iterations whose G-step falls where the
-    # global iteration index puts it (i % n_critic == 0): blocks then differ by SCHEDULE (6 or 7 G-steps in 20 iterations),
-    # not by noise.  In that case the number of blocks is rounded up to a multiple of n_critic (the start index advances by
-    # --steps per block, so n_critic consecutive blocks see every phase once) and the MEAN block time is reported.
+    # A --steps that is no multiple of n_critic ends a block inside a group of n_critic iterations and the next block
+    # continues there (GroupedTrainer.run_iterations: the group's per-iteration graphs): blocks then differ by SCHEDULE (6 or
+    # 7 G-steps and stacked generator forwards in 20 iterations), not by noise.  In that case the number of blocks is rounded
+    # up to a multiple of n_critic (n_critic consecutive blocks see every phase once) and the MEAN block time is reported.
     nc = eng.n_critic
     ragged = args.steps % nc != 0
     nblocks = max(1, args.repeats)

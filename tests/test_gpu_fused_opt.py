@@ -247,6 +247,41 @@ def test_grouped_head_merged_launches_are_bit_identical(graphs, switch, part, fe
         assert torch.equal(a, b), f"tensor {k} differs between the merged and the one-launch-each form"
 
 
+@pytest.mark.parametrize("graphs", [False, True])
+def test_run_iterations_cuts_groups_anywhere(graphs):
+    """GroupedTrainer.run_iterations(k): a caller that stops or starts inside a group of n_critic iterations (the driver's
+    --steps 20) replays the group's per-iteration pieces -- the same launches in the same order, so nine iterations cut as
+    2 + 5 + 2 leave every state tensor bit-identical to three whole groups."""
+    from wfd_gan_amd.engine import GroupedTrainer, TrainEngine
+    S, C, Z, B = 101, 6, 42, 16
+    X, y = O.synth_dataset(C, 30, S - 1, 10, 13, 122, seed=1)
+    dmin, dmax = X.min(0), X.max(0)
+    scale, min_ = O.scaler_params(dmin, dmax)
+    Xs = torch.from_numpy(X * scale + min_).float()
+    out = []
+    for cuts in ((2, 5, 2), None):
+        st = O.make_state(S, C, Z, dmin[0], dmax[0], seed=2, df_seed=3)
+        O.perturb_df_bn(st.DF, 4)
+        eng = TrainEngine(S, C, Z, B, st.scaler_min, st.scaler_max, {k: v.detach() for k, v in st.G.items()},
+                          {k: v.detach() for k, v in st.D.items()}, st.DF, device=DEV, seed=11, fuse_opt=True)
+        eng.attach_dataset(Xs, torch.from_numpy(y), shuffle_seed=5)
+        grp = GroupedTrainer(eng, graphs=graphs)
+        if cuts is None:
+            for _ in range(3):
+                grp.run_group()
+        else:
+            for k in cuts:
+                grp.run_iterations(k)
+            assert grp._phase == 0
+        torch.cuda.synchronize()
+        out.append([eng.Dp.flat.clone(), eng.Dp.sq.clone(), eng.Gp.flat.clone(), eng.Gp.sq.clone(), eng.iter_state.clone(),
+                    eng.gf_state.clone(), eng.buf["dacc"].clone(), eng.buf["gacc"].clone(), grp.stacked["XC"].clone(),
+                    torch.tensor([eng.nbt["model.3"], eng.nbt["model.6"], grp._pos])]
+                   + [v.clone() for v in eng.Gbuf.values()])
+    for k, (a, b) in enumerate(zip(*out)):
+        assert torch.equal(a, b), f"tensor {k} differs between the cut and the whole groups"
+
+
 @pytest.mark.parametrize("name", ["tiny", "cfg2"])
 def test_g_step_merged_launches_are_bit_identical(name, monkeypatch):
     """The G-step with its independent products of equal depth sharing launches (critic layer k beside observer FC layer k,

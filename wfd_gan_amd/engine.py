@@ -1379,6 +1379,8 @@ class GroupedTrainer:
             self.group.extend(r)
         self.group.extend(self.gstep)
         self._pos = 0
+        self._phase = 0                 # iterations of the current group already run by run_iterations()
+        self.part_plans = self.part_stages = None
         self.auto_reshuffle = True
         self.stages = None
         if graphs:
@@ -1464,6 +1466,8 @@ class GroupedTrainer:
     def run_group(self) -> int:
         """n_critic iterations: D D ... D G (the G-step belongs to the last one).  Returns n_critic."""
         eng, n = self.base, self.n
+        if self._phase:
+            raise RuntimeError("run_group() inside a group that run_iterations() has started; finish it with run_iterations()")
         if self.auto_reshuffle and self._pos + n > eng.iters_per_epoch:
             self.reshuffle()                 # the remaining < n_critic batches of the permutation are skipped
         if self.stages is not None:
@@ -1475,6 +1479,54 @@ class GroupedTrainer:
         eng.nbt["model.6"] += n + 1
         self._pos += n
         return n
+
+    def _build_parts(self):
+        """The group cut into one piece per iteration -- [head + D-step 0], [D-step 1], ..., [D-step n-1 + G-step] -- each
+        captured as a graph of its own: what run_iterations() replays when a caller stops or starts inside a group."""
+        eng = self.base
+        if self.obs is not None:
+            raise RuntimeError("run_iterations() is built for the single-lane group (observer_ahead=0)")
+        plans = []
+        for k in range(self.n):
+            p = Plan(self.ws, gemm_mode=eng.gemm_mode, wk=eng.wk)
+            if k == 0:
+                p.extend(self.head)
+            p.extend(self.rest[k])
+            if k == self.n - 1:
+                p.extend(self.gstep)
+            plans.append(p)
+        self.part_plans = plans
+        self.part_stages = [TrainEngine._capture_stages(p) for p in plans] if self.stages is not None else None
+        torch.cuda.synchronize()
+
+    def run_iterations(self, k: int) -> int:
+        """k consecutive iterations of the schedule D D ... D G, continuing where the previous call stopped: whole groups
+        go out as the group graph, a call that starts or stops inside a group replays that group's per-iteration pieces
+        (same launches in the same order, so the state after any number of iterations does not depend on how the calls
+        cut them)."""
+        eng, n, done = self.base, self.n, 0
+        while done < k:
+            if self._phase == 0 and k - done >= n:
+                self.run_group()
+                done += n
+                continue
+            if self.part_plans is None:
+                self._build_parts()
+            if self._phase == 0 and self.auto_reshuffle and self._pos + n > eng.iters_per_epoch:
+                self.reshuffle()
+            if self.part_stages is not None:
+                for st in self.part_stages[self._phase]:
+                    st()
+            else:
+                self.part_plans[self._phase].run()
+            self._phase += 1
+            done += 1
+            if self._phase == n:            # the group is complete: the bookkeeping run_group() does
+                self._phase = 0
+                eng.nbt["model.3"] += n + 1
+                eng.nbt["model.6"] += n + 1
+                self._pos += n
+        return k
 
     def reshuffle(self):
         eng = self.base
