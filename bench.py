@@ -325,7 +325,7 @@ def main():
     samp = None
     if not args.no_sampling:
         from wfd_gan_amd.sampler import BulkSampler
-        chunk = 8192
+        chunk = 32768           # 0.62 of the f32 MFMA peak at 8192 rows per chunk, 0.65 from 16384 on (tools/sampler_chunk_sweep.py)
         bs = BulkSampler(eng.generator_state(), args.seq_len, args.classes, args.latent_dim, dmin, dmax, chunk=chunk,
                          device=device, seed=99 + rank)
         bs.capture()
@@ -334,7 +334,7 @@ def main():
             bs.run_chunk(labels)
         barrier()
         t1 = time.perf_counter()
-        nchunks = 8
+        nchunks = 4
         for _ in range(nchunks):
             bs.run_chunk(labels)
         barrier()
