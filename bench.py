@@ -246,6 +246,8 @@ def main():
     rank, world, local = parallel.init_from_env()
     if world != args.gpus and world > 1:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    if os.environ.get("WFD_DIST_BACKEND") == "gloo" and local >= torch.cuda.device_count():
+        local %= torch.cuda.device_count()          # test rig: several gloo ranks sharing one GPU (never a measurement)
     device = torch.device(f"cuda:{local}")
     torch.cuda.set_device(device)
     if args.force_dp and world == 1 and not torch.distributed.is_initialized():
