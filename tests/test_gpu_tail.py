@@ -137,3 +137,42 @@ def test_sampler_raises_where_reference_raises():
     bad.run_chunk(labels)
     with pytest.raises(IndexError):
         bad.check_length_index()
+
+
+@pytest.mark.parametrize("S", [41, 1401, 103, 64])
+def test_sampler_wide_access_forms_are_bit_identical(S):
+    """From 1024 rows on, the sampler's two row passes (sigmoid + length mask; inverse scaling + trimming + rounding) run
+    with four columns per thread and access (ep_sigmoid_lenmask_v4_kernel, sample_post_v4_kernel).  The same rows in one
+    1024-row call and in four 256-row calls (the one-column forms): identical fp32 output, length indices, integers and
+    lengths -- including rows whose length index cuts a group of four and rows that are all zero."""
+    from wfd_gan_amd._lib import lib
+    L = lib()
+    n, ld = 1024, (S + 3) // 4 * 4
+    g = torch.Generator().manual_seed(S)
+    P = (torch.randn(n, ld, generator=g) * 2).to(DEV)
+    P[:, 0] = torch.linspace(-6, 6, n)                 # length indices from 0 to S - 1
+    bias = (torch.randn(ld, generator=g) * 0.1).to(DEV)
+    dmin, dmax = np.zeros(S), np.linspace(S - 1.0, 3.0, S)
+    from wfd_gan_amd.sampler import minmax_params
+    scale, min_ = minmax_params(dmin, dmax)
+    sc, mn = torch.from_numpy(scale).to(DEV), torch.from_numpy(min_).to(DEV)
+    st = torch.cuda.current_stream().cuda_stream
+    res = []
+    for rows in (n, 256):
+        y = torch.full((n, ld), 7.0, device=DEV)
+        idx = torch.zeros(n, dtype=torch.int32, device=DEV)
+        err = torch.zeros(1, dtype=torch.int32, device=DEV)
+        out = torch.zeros(n, S, dtype=torch.int32, device=DEV)
+        lens = torch.zeros(n, dtype=torch.int32, device=DEV)
+        for a in range(0, n, rows):
+            L.ep_sigmoid_lenmask(P[a:].data_ptr(), 1, 0, ld, rows, S, bias.data_ptr(), float(S - 1), 0.0, y[a:].data_ptr(), ld,
+                                 idx[a:].data_ptr(), err.data_ptr(), st)
+            L.sample_post(y[a:].data_ptr(), ld, rows, S, mn.data_ptr(), sc.data_ptr(), out[a:].data_ptr(), S, lens[a:].data_ptr(),
+                          st)
+        torch.cuda.synchronize()
+        res.append((y, idx, out, lens))
+    for a, b in zip(*res):
+        assert torch.equal(a, b)
+    y, idx, out, lens = res[0]
+    assert torch.all(y[:, S:] == 7.0)                  # columns behind S - 1 are not touched
+    assert int(idx.min()) <= 8 and int(idx.max()) >= S - 8 and int(lens.max()) > 0      # short and full rows both occur

@@ -735,6 +735,48 @@ __global__ void ep_sigmoid_lenmask_kernel(const float* __restrict__ P, int ns, l
     }
 }
 
+// The same for an unsplit product with 16-byte aligned rows (bulk sampling: 32768 rows per chunk): four columns per thread and
+// access.  Columns of the last, partial group are handled one by one -- behind column S - 1 the output row may hold other
+// data (the one-hot columns of the critic's input).  Element for element the arithmetic of the kernel above.
+__global__ void ep_sigmoid_lenmask_v4_kernel(const float* __restrict__ P, int ldp, int S, const float* __restrict__ bias,
+                                             float range, float smin, float* __restrict__ out, int ldo,
+                                             int* __restrict__ idx_out, int* __restrict__ err, int rows_per_slot,
+                                             long slot_stride, unsigned long long* __restrict__ adv_state,
+                                             unsigned long long inc0, unsigned long long inc1) {
+    const int m = blockIdx.x;
+    if (adv_state && m == 0 && threadIdx.x == 0) { adv_state[0] += inc0; adv_state[1] += inc1; }
+    if (rows_per_slot > 0) out += (long)(m / rows_per_slot) * slot_stride - (long)(m / rows_per_slot) * rows_per_slot * ldo;
+    const float* __restrict__ prow = P + (long)m * ldp;
+    float* __restrict__ orow = out + (long)m * ldo;
+    const float y0 = 1.0f / (1.0f + expf(-(prow[0] + bias[0])));
+    const float bl = __fadd_rn(__fmul_rn(y0, range), smin);
+    long idx = (long)bl + 1;
+    if (idx >= S || idx < 0) {
+        if (threadIdx.x == 0) atomicOr(err, 1);
+        idx = idx < 0 ? 0 : S;
+    }
+    if (threadIdx.x == 0) idx_out[m] = (int)idx;
+    const int S4 = S >> 2;
+    for (int q = threadIdx.x; q < S4; q += blockDim.x) {
+        const int j = 4 * q;
+        float4 y = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (j < idx) {                    // groups wholly behind the length index are zeros without reading the product
+            const float4 p = *reinterpret_cast<const float4*>(prow + j);
+            const float4 b = *reinterpret_cast<const float4*>(bias + j);
+            y.x = 1.0f / (1.0f + expf(-(p.x + b.x)));
+            if (j + 1 < idx) y.y = 1.0f / (1.0f + expf(-(p.y + b.y)));
+            if (j + 2 < idx) y.z = 1.0f / (1.0f + expf(-(p.z + b.z)));
+            if (j + 3 < idx) y.w = 1.0f / (1.0f + expf(-(p.w + b.w)));
+        }
+        *reinterpret_cast<float4*>(orow + j) = y;
+    }
+    for (int j = 4 * S4 + threadIdx.x; j < S; j += blockDim.x) {
+        float y = 0.f;
+        if (j < idx) y = 1.0f / (1.0f + expf(-(prow[j] + bias[j])));
+        orow[j] = y;
+    }
+}
+
 // Gradient at the generator's last pre-activation (thread per column j, loops rows):
 //   dfake[m][j] = dscale * sumP[m][j] (D path, dscale = -1/B) + (j >= 1 ? dDF[m][j-1] : 0)
 //   dz[m][j]    = j < idx[m] ? dfake * y (1 - y) : 0, y = fake[m][j];   dbias[j] = sum_m dz
@@ -1274,11 +1316,21 @@ int wfd_bn_bwd_tall(const float* P, int ns, long ss, int ldp, int M, int N, cons
     return WFD_OK;
 }
 
+// many rows of an unsplit, 16-byte aligned product: the four-columns-per-thread form
+static bool lenmask_v4(const float* P, int ns, int ldp, int M, const float* bias, const float* out, int ldo, long slot_stride) {
+    const uintptr_t a = (uintptr_t)P | (uintptr_t)bias | (uintptr_t)out;
+    return ns == 1 && M >= 1024 && (a & 15) == 0 && (ldp & 3) == 0 && (ldo & 3) == 0 && (slot_stride & 3) == 0;
+}
+
 int wfd_ep_sigmoid_lenmask(const float* P, int ns, long ss, int ldp, int M, int S, const float* bias, float range,
                            float smin, float* out, int ldo, int* idx, int* err, void* stream) {
     if (!P || !bias || !out || !idx || !err) return WFD_ERR_ARG;
-    hipLaunchKernelGGL(ep_sigmoid_lenmask_kernel, dim3(M), dim3(512), 0, (hipStream_t)stream, P, ns, ss, ldp, S, bias,
-                       range, smin, out, ldo, idx, err, 0, 0l, (unsigned long long*)nullptr, 0ull, 0ull);
+    if (lenmask_v4(P, ns, ldp, M, bias, out, ldo, 0))
+        hipLaunchKernelGGL(ep_sigmoid_lenmask_v4_kernel, dim3(M), dim3(256), 0, (hipStream_t)stream, P, ldp, S, bias, range, smin,
+                           out, ldo, idx, err, 0, 0l, (unsigned long long*)nullptr, 0ull, 0ull);
+    else
+        hipLaunchKernelGGL(ep_sigmoid_lenmask_kernel, dim3(M), dim3(512), 0, (hipStream_t)stream, P, ns, ss, ldp, S, bias,
+                           range, smin, out, ldo, idx, err, 0, 0l, (unsigned long long*)nullptr, 0ull, 0ull);
     WFD_CHECK_LAUNCH();
     return WFD_OK;
 }

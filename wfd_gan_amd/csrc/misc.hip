@@ -280,6 +280,52 @@ __global__ void sample_post_kernel(const float* __restrict__ Y, int ldy, int S, 
 }
 
 
+// The same with 16-byte loads of the fp32 row (ldy % 4 == 0, Y 16-byte aligned): the bulk sampler's form.
+__global__ void sample_post_v4_kernel(const float* __restrict__ Y, int ldy, int S, const double* __restrict__ min_,
+                                      const double* __restrict__ scale_, int* __restrict__ out, int ldo,
+                                      int* __restrict__ len_out) {
+    extern __shared__ float xs[];
+    __shared__ int s_lo, s_hi;
+    const int m = blockIdx.x;
+    if (threadIdx.x == 0) { s_lo = S; s_hi = -1; }
+    __syncthreads();
+    int lo = S, hi = -1;
+    const float* __restrict__ yrow = Y + (long)m * ldy;
+    const int S4 = S >> 2;
+    for (int q = threadIdx.x; q < S4; q += blockDim.x) {
+        const int j = 4 * q;
+        const float4 y = *reinterpret_cast<const float4*>(yrow + j);
+        const float yy[4] = {y.x, y.y, y.z, y.w};
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            float x = (float)((double)yy[k] - min_[j + k]);
+            x = (float)((double)x / scale_[j + k]);
+            xs[j + k] = x;
+            if (x != 0.f) { lo = min(lo, j + k); hi = max(hi, j + k); }
+        }
+    }
+    for (int j = 4 * S4 + threadIdx.x; j < S; j += blockDim.x) {
+        float x = (float)((double)yrow[j] - min_[j]);
+        x = (float)((double)x / scale_[j]);
+        xs[j] = x;
+        if (x != 0.f) { lo = min(lo, j); hi = max(hi, j); }
+    }
+    atomicMin(&s_lo, lo);
+    atomicMax(&s_hi, hi);
+    __syncthreads();
+    lo = s_lo; hi = s_hi;
+    const int n = hi >= lo ? hi - lo + 1 : 0;
+    for (int j = threadIdx.x; j < S; j += blockDim.x) {
+        int v = 0;
+        if (j < n) {
+            v = (int)rintf(xs[lo + j]);
+            if (v == 0) v = 1;
+        }
+        out[(long)m * ldo + j] = v;
+    }
+    if (threadIdx.x == 0) len_out[m] = n;
+}
+
 // The sampler epilogues of the generator's other consumers, selected by `mode` (x = inverse_transform(y) as above):
 //   0 generate.py:59-63      trim zeros of x at both ends, rint, 0 -> 1                      (= sample_post_kernel)
 //   1 gan_wt.py:79-87        len = min(int(x0), S-1) made even; out = rint(x[1 .. 1+len)), 0 -> 1
@@ -659,8 +705,12 @@ int wfd_sample_post_mode(const float* Y, int ldy, int M, int S, const double* mi
 int wfd_sample_post(const float* Y, int ldy, int M, int S, const double* min_, const double* scale_, int* out, int ldo,
                     int* len_out, void* stream) {
     if (!Y || !min_ || !scale_ || !out || !len_out || (size_t)S * 4 > 60000) return WFD_ERR_ARG;
-    hipLaunchKernelGGL(sample_post_kernel, dim3(M), dim3(256), (size_t)S * sizeof(float), (hipStream_t)stream, Y, ldy, S,
-                       min_, scale_, out, ldo, len_out);
+    if (M >= 1024 && ((uintptr_t)Y & 15) == 0 && (ldy & 3) == 0)
+        hipLaunchKernelGGL(sample_post_v4_kernel, dim3(M), dim3(256), (size_t)S * sizeof(float), (hipStream_t)stream, Y, ldy, S,
+                           min_, scale_, out, ldo, len_out);
+    else
+        hipLaunchKernelGGL(sample_post_kernel, dim3(M), dim3(256), (size_t)S * sizeof(float), (hipStream_t)stream, Y, ldy, S,
+                           min_, scale_, out, ldo, len_out);
     WFD_CHECK_LAUNCH();
     return WFD_OK;
 }
