@@ -207,19 +207,19 @@ __global__ __launch_bounds__(1024) void g_tail_kernel(const float* __restrict__ 
 // block: one sample x 64 positions; LDS holds dC rows l0-4 .. l0+66.
 __global__ void conv1_bwd_kernel(const float* __restrict__ dC, int L, int Cout, const float* __restrict__ W,
                                  float* __restrict__ dX, int lddx) {
-    extern __shared__ float sm[];
-    const int CS = Cout + 1;           // padded row: the 16 positions a wave reads per channel fall in 16 banks
-    float* ds = sm;                    // [71][Cout + 1]
+    extern __shared__ __attribute__((aligned(16))) float sm[];
+    const int CS = Cout + 4;           // padded row (Cout % 4 == 0): 16-byte aligned for ds_write_b128, and the 16 positions x
+                                       // 4 channel phases a wave reads at a time fall in 64 different banks (36 l + q mod 64)
+    float* ds = sm;                    // [71][Cout + 4]
     float* ws = sm + 71 * CS;          // [Cout][8]
     const int b = blockIdx.y, l0 = blockIdx.x * 64, tid = threadIdx.x;
     const int q4 = Cout >> 2;
-    for (int i = tid; i < 71 * q4; i += blockDim.x) {          // 16-byte loads, scalar stores into the padded rows
+    for (int i = tid; i < 71 * q4; i += blockDim.x) {          // 16-byte loads, 16-byte stores into the padded rows
         const int r = i / q4, c0 = 4 * (i - r * q4);
         const int l = l0 - 4 + r;
         float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
         if (l >= 0 && l < L) v = *reinterpret_cast<const float4*>(dC + ((long)b * L + l) * Cout + c0);
-        float* d = ds + r * CS + c0;
-        d[0] = v.x; d[1] = v.y; d[2] = v.z; d[3] = v.w;
+        *reinterpret_cast<float4*>(ds + r * CS + c0) = v;
     }
     for (int i = tid; i < Cout * 8; i += blockDim.x) ws[i] = W[i];
     __syncthreads();
@@ -302,7 +302,7 @@ int wfd_g_loss(const float* ce, int B, const float* head, float alpha, float* ou
 
 int wfd_df_conv1_bwd(const float* dC, int Bn, int L, int Cout, const float* W, float* dX, int lddx, void* stream) {
     if (!dC || !W || !dX || Cout > 64 || (Cout & 3)) return WFD_ERR_ARG;
-    const size_t sm = (size_t)(71 * (Cout + 1) + 8 * Cout) * sizeof(float);
+    const size_t sm = (size_t)(71 * (Cout + 4) + 8 * Cout) * sizeof(float);
     hipLaunchKernelGGL(conv1_bwd_kernel, dim3(cdiv(L, 64), Bn), dim3(256), sm, (hipStream_t)stream, dC, L, Cout, W, dX,
                        lddx);
     WFD_CHECK_LAUNCH();
