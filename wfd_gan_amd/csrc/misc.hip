@@ -135,8 +135,8 @@ __device__ __forceinline__ void gather_row_body(const GatherArgs& a, int b) {
 __global__ void gather_batch_kernel(GatherArgs a) { gather_row_body(a, blockIdx.x); }
 
 // Everything a group of n_critic iterations draws before its first product, in ONE launch: the dropout keep-masks of its
-// critic passes and of its G-step (blocks [0, mblocks * nslots)), the gathered real batches with their one-hot columns
-// (the next gblocks blocks, one per row), and the generator's normal inputs (the last zblocks).  The three parts write
+// critic passes and of its G-step (the last mblocks * nslots blocks), the gathered real batches with their one-hot columns
+// (the first gblocks blocks, one per row), and the generator's normal inputs (the next zblocks).  The three parts write
 // disjoint memory; each is the body of the kernel it replaces.
 struct GroupInputs {
     MaskSlots m; int nslots, mblocks; float p; const unsigned long long* mstate;
@@ -144,13 +144,17 @@ struct GroupInputs {
     unsigned long long zseed; int zblocks, zrows;
 };
 __global__ void group_inputs_kernel(GroupInputs a) {
+    // the gathered rows first: each is a chain of four dependent loads (cursor -> permutation -> label / data row), which then
+    // runs under the mask generation instead of behind it
     int b = blockIdx.x;
-    const int nm = a.mblocks * a.nslots;
-    if (b < nm) { mask_slot_body(a.m, b / a.mblocks, b % a.mblocks, a.mblocks, a.p, a.mstate); return; }
-    b -= nm;
     if (b < a.gblocks) { gather_row_body(a.g, b); return; }
     b -= a.gblocks;
-    normal_rows_body(a.g.zin, a.g.ldz, a.zrows, a.g.Z, a.zseed, a.g.state ? a.g.state[0] : 0ull, b, a.zblocks);
+    if (b < a.zblocks) {
+        normal_rows_body(a.g.zin, a.g.ldz, a.zrows, a.g.Z, a.zseed, a.g.state ? a.g.state[0] : 0ull, b, a.zblocks);
+        return;
+    }
+    b -= a.zblocks;
+    mask_slot_body(a.m, b / a.mblocks, b % a.mblocks, a.mblocks, a.p, a.mstate);
 }
 
 // z rows and the dropout keep-masks of one step in a single launch (same streams as the two kernels above:
