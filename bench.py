@@ -98,6 +98,7 @@ def gemm_roofline(eng, plans=None, rep=16, rounds=3):
     state.  Per-launch time = replay time / rep, which amortises the event pair and the graph launch and keeps the
     host out of the measurement.  achieved = sum(flops) / sum(time) over the launches of the group, weighted as they
     occur (D-step launches x3)."""
+    from wfd_gan_amd.parallel import graph_capture_kwargs
     from wfd_gan_amd.plan import FORK, HOST, JOIN
     L = eng.L
     gemm_fns = {L.gemm_f32: "gemm", L.conv8_gemm_f32: "conv", L.gemm_f32_fused: "gemm_fused",
@@ -146,7 +147,7 @@ def gemm_roofline(eng, plans=None, rep=16, rounds=3):
     per_call = []
     for fn, a, fl, weight in calls:
         g = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(g):
+        with torch.cuda.graph(g, **graph_capture_kwargs()):
             st = torch.cuda.current_stream().cuda_stream
             for _ in range(rep):
                 fn(*a, st)
@@ -478,6 +479,11 @@ def main():
             out["cpu_baseline"] = cpu_baseline(args, args.cpu_seconds)
         print(json.dumps(out), flush=True)
     if torch.distributed.is_initialized():
+        # the engines (and their HIP graphs with captured RCCL nodes) go before the communicator does
+        import gc
+        del drv, eng
+        gc.collect()
+        torch.cuda.synchronize()
         torch.distributed.destroy_process_group()
 
 

@@ -127,8 +127,34 @@ def test_fast_mode_graph_equals_eager():
     assert torch.isfinite(e1.Dp.flat).all() and torch.isfinite(e1.Gp.flat).all()
 
 
+@pytest.fixture(scope="module")
+def nccl_world1():
+    """One 1-rank NCCL group for the whole module.  It is destroyed only after every engine that captured collectives into a
+    HIP graph has been released: a graph holding RCCL nodes of a destroyed communicator aborted the process once (a later,
+    unrelated allocation collected it)."""
+    import gc
+    import torch.distributed as dist
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29533")
+    mine = not dist.is_initialized()
+    if mine:
+        dist.init_process_group("nccl", rank=0, world_size=1)
+    yield
+    gc.collect()
+    torch.cuda.synchronize()
+    if mine:
+        dist.destroy_process_group()
+
+
 @pytest.mark.parametrize("captured", [True, False])
-def test_data_parallel_world1_nccl(captured, monkeypatch):
+def test_data_parallel_world1_nccl(captured, monkeypatch, nccl_world1):
+    import gc
+    _data_parallel_world1_nccl(captured, monkeypatch)
+    gc.collect()                      # the engines and their graphs go before the next test (and before the group does)
+    torch.cuda.synchronize()
+
+
+def _data_parallel_world1_nccl(captured, monkeypatch):
     """The data-parallel code path (bias gradients ahead of the weight gradients, bucketed asynchronous all-reduce over RCCL,
     flat optimizer pass) with a 1-rank NCCL group must reproduce the single-rank engine bit for bit -- with the collectives
     captured INSIDE the step graphs (one graph replay per D-step / G-step / group: the default on the "nccl" backend) and
@@ -136,11 +162,8 @@ def test_data_parallel_world1_nccl(captured, monkeypatch):
     import torch.distributed as dist
     from wfd_gan_amd.engine import GroupedTrainer, TrainEngine
     monkeypatch.setenv("WFD_DP_GRAPH", "1" if captured else "0")
-    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-    os.environ.setdefault("MASTER_PORT", "29533")
-    if not dist.is_initialized():
-        dist.init_process_group("nccl", rank=0, world_size=1)
-    try:
+    assert dist.is_initialized()
+    if True:
         S, C, Z, B = 41, 5, 16, 8
         st, e1, Xs, y = _setup(S, C, Z, B, "div")
         mk = lambda: TrainEngine(S, C, Z, B, e1.scaler_min, e1.scaler_max, e1.generator_state(), e1.discriminator_state(),
@@ -173,8 +196,6 @@ def test_data_parallel_world1_nccl(captured, monkeypatch):
             outs.append((e.Dp.flat.clone(), e.Gp.flat.clone(), e.buf["dacc"].clone()))
         for a, b in zip(*outs):
             assert torch.equal(a, b)
-    finally:
-        dist.destroy_process_group()
 
 
 def test_trainer_and_sampler_cli(tmp_path):

@@ -1091,7 +1091,8 @@ class TrainEngine:
         self.graph_group = None
         if len(self.graph_d) == 1 and len(self.graph_g) == 1:
             g = torch.cuda.CUDAGraph()
-            kw = dict(capture_error_mode="thread_local") if (self.fast_d.has_collectives or self.fast_g.has_collectives) else {}
+            from .parallel import graph_capture_kwargs
+            kw = graph_capture_kwargs()
             try:
                 with torch.cuda.graph(g, **kw):
                     self.fast_d.run()
@@ -1117,8 +1118,9 @@ class TrainEngine:
                 g = torch.cuda.CUDAGraph()
                 # collectives captured with the launches (RCCL): the backend's watchdog thread makes HIP calls of its own
                 # during the capture, which only the thread-local capture mode tolerates
+                from .parallel import graph_capture_kwargs
                 coll = st.has_collectives
-                kw = dict(capture_error_mode="thread_local") if coll else {}
+                kw = graph_capture_kwargs()             # (thread-local whenever a process group exists, collectives or not)
                 try:
                     with torch.cuda.graph(g, **kw):
                         st.run()

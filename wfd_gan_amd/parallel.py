@@ -38,6 +38,17 @@ def graph_capturable(group=None) -> bool:
     return dist.get_backend(group) == "nccl"
 
 
+def graph_capture_kwargs() -> dict:
+    """Keyword arguments for ``torch.cuda.graph(...)``.  Once a process group exists, its backend's watchdog thread makes
+    HIP calls of its own at any time (event queries on earlier collectives); under the default (global) capture mode such
+    a call from ANOTHER thread invalidates a capture that is in progress on this one -- also a capture that contains no
+    collective at all (seen as `hipErrorStreamCaptureInvalidated` / an abort of the watchdog).  The thread-local mode only
+    polices the capturing thread."""
+    if dist.is_available() and dist.is_initialized():
+        return dict(capture_error_mode="thread_local")
+    return {}
+
+
 def allreduce_sum_(flat: torch.Tensor, group=None) -> torch.Tensor:
     """In-place sum of a flat gradient buffer over all ranks (the optimizer applies the 1/world factor)."""
     dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=group)

@@ -137,7 +137,8 @@ class BulkSampler:
         torch.cuda.current_stream().wait_stream(side)
         torch.cuda.synchronize()
         self.graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(self.graph):
+        from .parallel import graph_capture_kwargs
+        with torch.cuda.graph(self.graph, **graph_capture_kwargs()):
             self.plan_rng.run()
             self.plan.run()
         torch.cuda.synchronize()
