@@ -590,8 +590,12 @@ inline bool use_conv8_c32(int M, int Cin, int Cout) { return Cin == C32 && (long
 // neighbouring tiles.  Dynamic LDS: 2 x (128 + 128) x 36 floats = 73.7 KB -> two workgroups per CU.
 constexpr int T128 = 128, T128_F = T128 * LDK;            // floats per operand tile
 
-template <bool EPI>
-__global__ __launch_bounds__(NTHREADS) void gemm_f32_nt128_kernel(GemmArgs g, int gx, int gy) {
+// PF2 (K % 32 == 0, >= 3 k-tiles): operand tiles are requested TWO k-tiles ahead into two register sets (the loop is unrolled
+// by two so that each set has a fixed role per half) -- with two waves per SIMD one k-tile of MFMAs (1.7 us) does not always
+// cover an HBM miss of the activation stream, two do; the wait in front of the LDS stores then only covers the OLDER set
+// (vmcnt leaves the younger set's 8 loads in flight).
+template <bool EPI, bool PF2 = false>
+__global__ __launch_bounds__(NTHREADS, 2) void gemm_f32_nt128_kernel(GemmArgs g, int gx, int gy) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1, i = lane & 31, h = lane >> 5;
@@ -631,18 +635,7 @@ __global__ __launch_bounds__(NTHREADS) void gemm_f32_nt128_kernel(GemmArgs g, in
             }
         }
     };
-    load_all(0);
-#pragma unroll
-    for (int q = 0; q < 2; ++q) {
-        store_tile<true, 4>(ra[q], smem + 64 * q * LDK, tid);
-        store_tile<true, 4>(rb[q], smem + T128_F + 64 * q * LDK, tid);
-    }
-    __syncthreads();
-    int cur = 0;
-    for (int kt = 0; kt < nk; ++kt) {
-        const bool more = kt + 1 < nk;
-        if (more) load_all((kt + 1) * BK);
-        const float* a_s = smem + cur * 2 * T128_F;
+    auto compute = [&](const float* a_s) __attribute__((always_inline)) {
         const float* b_s = a_s + T128_F;
 #pragma unroll
         for (int kk = 0; kk < 4; ++kk) {
@@ -660,16 +653,58 @@ __global__ __launch_bounds__(NTHREADS) void gemm_f32_nt128_kernel(GemmArgs g, in
                     for (int b = 0; b < 2; ++b)
                         acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[a][s2], bf[b][s2], acc[a][b], 0, 0, 0);
         }
-        if (more) {
-            float* nxt = smem + (cur ^ 1) * 2 * T128_F;
+    };
+    auto to_lds = [&](float (&xa)[2][8], float (&xb)[2][8], float* dst) __attribute__((always_inline)) {
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            store_tile<true, 4>(xa[q], dst + 64 * q * LDK, tid);
+            store_tile<true, 4>(xb[q], dst + T128_F + 64 * q * LDK, tid);
+        }
+    };
+    if constexpr (PF2) {
+        float rc[2][8], rd[2][8];                 // the second register set
+        auto load_fast = [&](float (&xa)[2][8], float (&xb)[2][8], int k0) __attribute__((always_inline)) {
 #pragma unroll
             for (int q = 0; q < 2; ++q) {
-                store_tile<true, 4>(ra[q], nxt + 64 * q * LDK, tid);
-                store_tile<true, 4>(rb[q], nxt + T128_F + 64 * q * LDK, tid);
+                load_tile_fast<true, false>(xa[q], g.A, offa[q], lpu, k0, k0, tid, 0, 0);
+                load_tile_fast<true, false>(xb[q], g.B, offb[q], lpu, k0, k0, tid, 0, 0);
             }
-        }
+        };
+        load_fast(ra, rb, 0);
+        to_lds(ra, rb, smem);
+        load_fast(rc, rd, BK);                    // tile 1 (host: nk >= 3)
         __syncthreads();
-        cur ^= 1;
+        int cur = 0;
+        for (int kt = 0; kt < nk; kt += 2) {
+            // even half: tile kt from LDS; (rc, rd) hold tile kt + 1, in flight; tile kt + 2 goes to (ra, rb)
+            if (kt + 2 < nk) load_fast(ra, rb, (kt + 2) * BK);
+            __builtin_amdgcn_sched_barrier(0);
+            compute(smem + cur * 2 * T128_F);
+            if (kt + 1 < nk) to_lds(rc, rd, smem + (cur ^ 1) * 2 * T128_F);
+            __syncthreads();
+            cur ^= 1;
+            if (kt + 1 >= nk) break;
+            // odd half: tile kt + 1; (ra, rb) hold tile kt + 2; tile kt + 3 goes to (rc, rd)
+            if (kt + 3 < nk) load_fast(rc, rd, (kt + 3) * BK);
+            __builtin_amdgcn_sched_barrier(0);
+            compute(smem + cur * 2 * T128_F);
+            if (kt + 2 < nk) to_lds(ra, rb, smem + (cur ^ 1) * 2 * T128_F);
+            __syncthreads();
+            cur ^= 1;
+        }
+    } else {
+        load_all(0);
+        to_lds(ra, rb, smem);
+        __syncthreads();
+        int cur = 0;
+        for (int kt = 0; kt < nk; ++kt) {
+            const bool more = kt + 1 < nk;
+            if (more) load_all((kt + 1) * BK);
+            compute(smem + cur * 2 * T128_F);
+            if (more) to_lds(ra, rb, smem + (cur ^ 1) * 2 * T128_F);
+            __syncthreads();
+            cur ^= 1;
+        }
     }
 #pragma unroll
     for (int a = 0; a < 2; ++a)
@@ -696,6 +731,18 @@ int launch_nt128(const GemmArgs& g, hipStream_t st) {
         attr = true;
     }
     const int gx = cdiv(g.N, T128), gy = cdiv(g.M, T128);
+    static const int pf2 = getenv("WFD_NT128_PF2") ? atoi(getenv("WFD_NT128_PF2")) : 1;        // (the switch: same-session A/B)
+    if (pf2 && g.K % BK == 0 && g.K >= 3 * BK) {
+        static bool attr2 = false;
+        if (!attr2) {
+            (void)hipFuncSetAttribute((const void*)gemm_f32_nt128_kernel<EPI, true>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                      (int)lds);
+            attr2 = true;
+        }
+        hipLaunchKernelGGL((gemm_f32_nt128_kernel<EPI, true>), dim3(gx * gy), dim3(NTHREADS), lds, st, g, gx, gy);
+        WFD_CHECK_LAUNCH();
+        return WFD_OK;
+    }
     hipLaunchKernelGGL((gemm_f32_nt128_kernel<EPI>), dim3(gx * gy), dim3(NTHREADS), lds, st, g, gx, gy);
     WFD_CHECK_LAUNCH();
     return WFD_OK;
