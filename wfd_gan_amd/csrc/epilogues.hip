@@ -491,6 +491,7 @@ __global__ __launch_bounds__(CTS * RG) void bn_train_relu_small_kernel(
     mean += (long)blockIdx.y * N; m2 += (long)blockIdx.y * N; invstd_out += (long)blockIdx.y * N;
     const bool ok = n < N;
     const float b = ok && bias ? bias[n] : 0.f;
+    const float ga = ok ? gamma[n] : 0.f, be = ok ? beta[n] : 0.f;        // requested with the rows, not behind the reductions
     float z[RPT];
     float s = 0.f;
 #pragma unroll
@@ -513,7 +514,6 @@ __global__ __launch_bounds__(CTS * RG) void bn_train_relu_small_kernel(
     q = rg_reduce_t<CTS>(q, red);
     if (!ok) return;
     const float istd = 1.0f / sqrtf(q / (float)M + eps);
-    const float ga = gamma[n], be = beta[n];
 #pragma unroll
     for (int r = 0; r < RPT; ++r) {
         const int m = rg + RG * r;
@@ -672,16 +672,26 @@ __global__ __launch_bounds__(CTS * RG) void bn_bwd_small_kernel(
     __shared__ float red[RG][CTS];
     const int n = blockIdx.x * CTS + threadIdx.x, rg = threadIdx.y;
     const bool ok = n < N;
-    float dy[RPT], xh[RPT];
-    float s0 = 0.f, s1 = 0.f;
+    // every global load of the launch up front: the column's gamma / 1/std (read behind the reductions they were a dependent
+    // round trip in front of the stores), and the product unconditionally instead of behind the load of H that masks it
+    const float k = ok ? gamma[n] * invstd[n] : 0.f;
+    float dy[RPT], xh[RPT], hv[RPT];
 #pragma unroll
     for (int r = 0; r < RPT; ++r) {
         const int m = rg + RG * r;
-        dy[r] = 0.f; xh[r] = 0.f;
+        dy[r] = 0.f; xh[r] = 0.f; hv[r] = 0.f;
         if (ok && m < M) {
             const long o = (long)m * ldh + n;
-            dy[r] = H[o] > 0.f ? slab_sum(P, ns, ss, (long)m * ldp + n) : 0.f;
+            hv[r] = H[o];
+            dy[r] = slab_sum(P, ns, ss, (long)m * ldp + n);
             xh[r] = XH[o];
+        }
+    }
+    float s0 = 0.f, s1 = 0.f;
+#pragma unroll
+    for (int r = 0; r < RPT; ++r) {
+        if (ok && rg + RG * r < M) {
+            dy[r] = hv[r] > 0.f ? dy[r] : 0.f;
             s0 += dy[r];
             s1 = __fmaf_rn(dy[r], xh[r], s1);
         }
@@ -690,7 +700,7 @@ __global__ __launch_bounds__(CTS * RG) void bn_bwd_small_kernel(
     s1 = rg_reduce_t<CTS>(s1, red);
     float sb = 0.f;
     if (ok) {
-        const float k = gamma[n] * invstd[n], a0 = s0 / count, a1 = s1 / count;
+        const float a0 = s0 / count, a1 = s1 / count;
 #pragma unroll
         for (int r = 0; r < RPT; ++r) {
             const int m = rg + RG * r;
