@@ -75,6 +75,12 @@ int wfd_gemm_f32_fused(int layout, const float* A, int lda, const float* B, int 
 int wfd_conv8_gemm_f32_fused(const float* X, int Bn, int L, int Cin, int pad, const float* Wp, int Cout, float* out,
                              int ldo, int epi, const float* scale, const float* shift, int act, const float* D, int ldd,
                              int dmode, void* stream);
+/* wfd_conv8_gemm_f32_fused (epi 1: conv + folded eval BatchNorm + activation, src/model.py:91-104,140-176) whose launch also
+ * writes the following MyMaxPool1dPadSame(8, 8) (src/model.py:107-131) of its output to PO[Bn][L/8][Cout] -- the values of
+ * wfd_df_pool8_fwd.  Only for Cin = 32, pad = 3, L % 8 == 0, f32 operand mode and a product large enough for the
+ * LDS-resident conv form (wfd_conv8_direct); WFD_ERR_ARG otherwise (issue the two launches). */
+int wfd_conv8_gemm_f32_fused_pool(const float* X, int Bn, int L, int Cin, int pad, const float* Wp, int Cout, float* out,
+                                  int ldo, const float* scale, const float* shift, int act, float* PO, void* stream);
 
 /* Small-batch form of the same contractions + consumers: the K split runs INSIDE the workgroup (one 32x32 or 32x16 output
  * tile per workgroup, its 2-8 waves each contract a k-range with exact-f32 MFMAs and fold through LDS in wave order), so

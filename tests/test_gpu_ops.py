@@ -350,3 +350,39 @@ def test_g_tail_equals_its_three_launches(B, C):
     want = torch.nn.functional.cross_entropy(logits[sel][:, :C].double(), labels[sel].long()) if sel.any() else torch.tensor(0.0)
     assert abs(float(outs[0][3][1]) - float(want)) <= 1e-5 * max(1.0, abs(float(want)))
     assert float(outs[0][3][3]) == float(sel.sum())
+
+
+@pytest.mark.parametrize("Bn,L,Cout,act", [(16, 1400, 32, 2), (13, 1400, 32, 1), (12, 1408, 64, 2), (64, 1400, 32, 2)])
+def test_conv8_fused_pool_matches_the_two_launches(Bn, L, Cout, act):
+    """wfd_conv8_gemm_f32_fused_pool: the Cin = 32 conv + folded BatchNorm + activation whose launch also writes the
+    following max-pool (k = 8, stride 8, zero padding taking part) from its accumulators, against wfd_conv8_gemm_f32_fused +
+    wfd_df_pool8_fwd: the activation and the pooled rows must be bit-identical (the row grid is shifted by three rows, the
+    arithmetic per element is not touched), including the first window of every sample (left padding) and samples whose
+    last three positions lie in no window."""
+    from wfd_gan_amd._lib import lib
+    L_ = lib()
+    g = torch.Generator().manual_seed(Bn * L + Cout)
+    X = torch.randn(Bn * L, 32, generator=g).to(DEV)
+    W = (torch.randn(Cout, 256, generator=g) * 0.08).to(DEV)
+    scale = (torch.rand(Cout, generator=g) + 0.5).to(DEV)
+    shift = (torch.randn(Cout, generator=g) * 0.3 - 0.4).to(DEV)          # mostly negative: windows whose maximum is the padding
+    st = torch.cuda.current_stream().cuda_stream
+    Lout = L // 8
+    y1 = torch.full((Bn * L, Cout), 9.0, device=DEV); p1 = torch.full((Bn * Lout, Cout), 9.0, device=DEV)
+    y2 = torch.full((Bn * L, Cout), 8.0, device=DEV); p2 = torch.full((Bn * Lout, Cout), 8.0, device=DEV)
+    L_.conv8_gemm_f32_fused(X.data_ptr(), Bn, L, 32, 3, W.data_ptr(), Cout, y1.data_ptr(), Cout, 1, scale.data_ptr(),
+                            shift.data_ptr(), act, 0, 0, 0, st)
+    L_.df_pool8_fwd(y1.data_ptr(), Bn, L, Cout, p1.data_ptr(), st)
+    L_.conv8_gemm_f32_fused_pool(X.data_ptr(), Bn, L, 32, 3, W.data_ptr(), Cout, y2.data_ptr(), Cout, scale.data_ptr(),
+                                 shift.data_ptr(), act, p2.data_ptr(), st)
+    torch.cuda.synchronize()
+    assert torch.equal(y1, y2)
+    assert torch.equal(p1, p2)
+    assert float((p1 == 0).float().mean()) > 0.0005 or act != 1      # relu: some windows are won by a zero
+    # rejected shapes fall back in the caller: L % 8 != 0, the small form
+    with pytest.raises(Exception):
+        L_.conv8_gemm_f32_fused_pool(X.data_ptr(), Bn, L - 4, 32, 3, W.data_ptr(), Cout, y2.data_ptr(), Cout, scale.data_ptr(),
+                                     shift.data_ptr(), act, p2.data_ptr(), st)
+    with pytest.raises(Exception):
+        L_.conv8_gemm_f32_fused_pool(X.data_ptr(), 2, L, 32, 3, W.data_ptr(), Cout, y2.data_ptr(), Cout, scale.data_ptr(),
+                                     shift.data_ptr(), act, p2.data_ptr(), st)

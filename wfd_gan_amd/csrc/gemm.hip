@@ -463,8 +463,10 @@ __global__ __launch_bounds__(NTHREADS) void conv8_c32_kernel(GemmArgs g, int cpw
     // input rows of a chunk travel global -> registers -> LDS; the next chunk's are in flight during the MFMA block
     constexpr int XN = (C32_ROWS + 7) * 8, XQ = (XN + NTHREADS - 1) / NTHREADS;
     float4 xr[XQ];
+    // pooled forward: the row grid is shifted by -3, so that every wave's 32 rows are four whole pooling windows
+    const int shift = (EPI && g.pool_out) ? 3 : 0;
     auto load_x = [&](int chunk) {
-        const long base = (long)chunk * C32_ROWS - pad;
+        const long base = (long)chunk * C32_ROWS - pad - shift;
 #pragma unroll
         for (int u = 0; u < XQ; ++u) {
             const int c = tid + u * NTHREADS;
@@ -485,9 +487,9 @@ __global__ __launch_bounds__(NTHREADS) void conv8_c32_kernel(GemmArgs g, int cpw
         __syncthreads();
         if (ch + 1 < c1) load_x(ch + 1);
 
-        const int m0 = ch * C32_ROWS;
+        const int m0 = ch * C32_ROWS - shift;
         const int mrow = m0 + wave * 32 + i;       // the output row whose A values this lane feeds
-        const int l = mrow < g.M ? mrow % L : -(1 << 20);
+        const int l = (mrow >= 0 && mrow < g.M) ? mrow % L : -(1 << 20);
         f32x16 acc;
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[r] = 0.f;
@@ -507,7 +509,7 @@ __global__ __launch_bounds__(NTHREADS) void conv8_c32_kernel(GemmArgs g, int cpw
             const int pcol = min(n0 + i, g.N - 1);
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const int prow = min(m0 + wave * 32 + (r & 3) + 8 * (r >> 2) + 4 * h, g.M - 1);
+                const int prow = max(min(m0 + wave * 32 + (r & 3) + 8 * (r >> 2) + 4 * h, g.M - 1), 0);
                 dv[r] = g.D[(long)prow * g.ldd + pcol];
             }
         }
@@ -526,11 +528,14 @@ __global__ __launch_bounds__(NTHREADS) void conv8_c32_kernel(GemmArgs g, int cpw
             }
         }
         const int col = n0 + i;
+        float pv[16];                              // activated outputs as the pool sees them (pad / foreign rows: 0)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) pv[r] = 0.f;
         if (col < g.N) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int row = m0 + wave * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
-                if (row < g.M) {
+                if (row >= 0 && row < g.M) {
                     if constexpr (EPI) {
                         if (pfd) {
                             float v = acc[r];
@@ -546,12 +551,34 @@ __global__ __launch_bounds__(NTHREADS) void conv8_c32_kernel(GemmArgs g, int cpw
                             else if (g.act == 2) v = v > 0.f ? v : elu_expm1(v);
                             else if (g.act == 3) v = 1.0f / (1.0f + expf(-v));
                             g.P[(long)row * g.ldp + col] = v;
+                            // the last three positions of a sample lie in no window of their own: in this tiling they are
+                            // the left padding of the next sample's first window, which counts as 0
+                            pv[r] = (row % L < L - 3) ? v : 0.f;
                         } else {
                             epi_store(g, g.P, acc[r], row, col);
                         }
                     } else {
                         g.P[(long)row * g.ldp + col] = acc[r];
                     }
+                }
+            }
+        }
+        if constexpr (EPI) {
+            if (g.pool_out) {
+                // window w of this wave = its rows 8w .. 8w + 7: registers 4w .. 4w + 3 of the lower (h = 0) and of the upper
+                // half-wave; the comparison is pool8_fwd_kernel's (v > mx ? v : mx from -inf)
+                const int nwin = g.M >> 3;         // = Bn * L / 8
+#pragma unroll
+                for (int w = 0; w < 4; ++w) {
+                    float mx = -INFINITY;
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) mx = pv[4 * w + q] > mx ? pv[4 * w + q] : mx;
+                    const float other = __shfl_xor(mx, 32, 64);
+                    // rows 8w .. 8w + 3 come first in the window: lower half, then upper half
+                    const float lo = h == 0 ? mx : other, hi = h == 0 ? other : mx;
+                    const float res = hi > lo ? hi : lo;
+                    const int wid = (m0 + wave * 32 + 8 * w + 3) >> 3;
+                    if (h == 0 && col < g.N && wid < nwin) g.pool_out[(long)wid * g.N + col] = res;
                 }
             }
         }
@@ -573,7 +600,7 @@ int launch_conv8_c32(const GemmArgs& g, hipStream_t st) {
         (void)hipFuncSetAttribute((const void*)conv8_c32_kernel<EPI>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         attr = true;
     }
-    const int nchunks = cdiv(g.M, C32_ROWS), gy = cdiv(g.N, 32), cpw = conv8_c32_cpw(nchunks, gy);
+    const int nchunks = cdiv(g.M + ((EPI && g.pool_out) ? 3 : 0), C32_ROWS), gy = cdiv(g.N, 32), cpw = conv8_c32_cpw(nchunks, gy);
     hipLaunchKernelGGL((conv8_c32_kernel<EPI>), dim3(cdiv(nchunks, cpw), gy), dim3(NTHREADS), lds, st, g, cpw, nchunks);
     WFD_CHECK_LAUNCH();
     return WFD_OK;
@@ -1104,6 +1131,25 @@ int wfd_conv8_gemm_f32_fused(const float* X, int Bn, int L, int Cin, int pad, co
     if (g_gemm_mode) return wfd_mx_launch(g, 3, 1, g_gemm_mode, (hipStream_t)stream);
     if (use_conv8_c32(g.M, Cin, Cout)) return launch_conv8_c32<true>(g, (hipStream_t)stream);
     return launch_gemm<true, true, true>(g, 1, true, true, (hipStream_t)stream);
+}
+
+// wfd_conv8_gemm_f32_fused (epi 1) whose launch also writes the max-pool of its output (wfd_df_pool8_fwd's values) to PO:
+// only the LDS-resident Cin = 32 form on the f32 pipe with L % 8 == 0 and pad = 3 can (WFD_ERR_ARG otherwise: the caller then
+// issues the two launches).
+int wfd_conv8_gemm_f32_fused_pool(const float* X, int Bn, int L, int Cin, int pad, const float* Wp, int Cout, float* out,
+                                  int ldo, const float* scale, const float* shift, int act, float* PO, void* stream) {
+    if (!X || !Wp || !out || !PO || Bn <= 0 || L <= 0 || (L & 7) || Cin != C32 || Cout <= 0 || ldo < Cout || pad != 3)
+        return WFD_ERR_ARG;
+    if (!aligned16(X) || !aligned16(Wp) || !fits31((long)Bn * L, Cin) || g_gemm_mode != 0) return WFD_ERR_ARG;
+    if (!use_conv8_c32(Bn * L, Cin, Cout)) return WFD_ERR_ARG;
+    GemmArgs g{};
+    g.A = X; g.B = Wp; g.P = out; g.M = Bn * L; g.N = Cout; g.K = 8 * Cin; g.lda = Cin; g.ldb = 8 * Cin; g.ldp = ldo;
+    g.ktiles_per_split = cdiv(g.K, BK);
+    g.convL = L; g.convCin = Cin; g.convPad = pad;
+    g.narrow = Cout <= 32;
+    g.epi = 1; g.act = act; g.scale = scale; g.shift = shift;
+    g.pool_out = PO;
+    return launch_conv8_c32<true>(g, (hipStream_t)stream);
 }
 
 // Weight gradient of the k=8 "SAME" conv (DF observer training, src/train_df.py:121-131 backward):

@@ -22,6 +22,10 @@ struct GemmArgs {
     const float* D;
     float* sq;
     float lr, alpha, eps;
+    // conv8_c32 forward only: != 0 -> the launch also writes the k = 8 / stride 8 max-pool (window j = rows 8j - 3 .. 8j + 4
+    // of a sample, zero padding taking part: MyMaxPool1dPadSame, src/model.py:107-131) of its activated output,
+    // pool_out[(b * L/8 + j) * N + n]; needs L % 8 == 0 (the same window phase in every sample)
+    float* pool_out;
 };
 
 static __device__ __forceinline__ float epi_apply(const GemmArgs& g, float v, int row, int col) {

@@ -166,11 +166,12 @@ def observer_forward(p: Plan, df: "ObserverDF", X, ldx: int, xoff: int, B: int, 
     cur, lvl, pi = Y[0], 0, 0
     for k in range(1, 7):
         c = cv[k]
-        p.conv8_affine(cur, B, Ls[lvl], c["cin"], 3, c["w"], c["cout"], c["scale"], c["shift"], c["act"], Y[k])
-        cur = Y[k]
         if c["pool"]:
-            p.add(L.df_pool8_fwd, ptr(cur), B, Ls[lvl], c["cout"], ptr(PO[pi]))
+            p.conv8_affine_pool(cur, B, Ls[lvl], c["cin"], 3, c["w"], c["cout"], c["scale"], c["shift"], c["act"], Y[k], PO[pi])
             cur, lvl, pi = PO[pi], lvl + 1, pi + 1
+        else:
+            p.conv8_affine(cur, B, Ls[lvl], c["cin"], 3, c["w"], c["cout"], c["scale"], c["shift"], c["act"], Y[k])
+            cur = Y[k]
     if convs_only:
         return
     for step in observer_fc_steps(p, df, B, PO, F1, F2, LOG, ldc):

@@ -425,6 +425,19 @@ class Plan:
         else:
             self.affine_act(self.conv8(X, Bn, L, Cin, pad, Wp, Cout), scale, shift, act, out, Cout)
 
+    def conv8_affine_pool(self, X, Bn, L, Cin, pad, Wp, Cout, scale, shift, act, out, PO):
+        """conv8_affine followed by the k = 8 / stride 8 max-pool of its output; one launch where the LDS-resident Cin = 32
+        form applies (wfd_conv8_gemm_f32_fused_pool), else the two launches."""
+        fuse = (self.gemm_mode == 0 and Cin == 32 and pad == 3 and L % 8 == 0 and scale is not None and shift is not None
+                and not self.conv_wk_cfg(X, Wp, Bn * L, Cin, Cout) and self.L.conv8_direct_mode(Bn * L, Cin, Cout, 0)
+                and os.environ.get("WFD_POOL_FUSE", "1") != "0")          # (the switch: same-session A/B)
+        if fuse:
+            self.add(self.L.conv8_gemm_f32_fused_pool, ptr(X), Bn, L, Cin, pad, ptr(Wp), Cout, ptr(out), Cout, ptr(scale),
+                     ptr(shift), act, ptr(PO))
+        else:
+            self.conv8_affine(X, Bn, L, Cin, pad, Wp, Cout, scale, shift, act, out)
+            self.add(self.L.df_pool8_fwd, ptr(out), Bn, L, Cout, ptr(PO))
+
     def conv8_mul(self, X, Bn, L, Cin, pad, Wp, Cout, D, ldd, dmode, colscale, out):
         cfg = self.conv_wk_cfg(X, Wp, Bn * L, Cin, Cout)
         if cfg:
