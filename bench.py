@@ -102,7 +102,7 @@ def gemm_roofline(eng, plans=None, rep=16, rounds=3):
     from wfd_gan_amd.plan import FORK, HOST, JOIN
     L = eng.L
     gemm_fns = {L.gemm_f32: "gemm", L.conv8_gemm_f32: "conv", L.gemm_f32_fused: "gemm_fused",
-                L.conv8_gemm_f32_fused: "conv", L.gemm_f32_pair: "pair", L.gemm_f32_wk: "gemm_wk", L.conv8_f32_wk: "conv",
+                L.conv8_gemm_f32_fused: "conv", L.conv8_gemm_f32_fused_pool: "conv", L.gemm_f32_pair: "pair", L.gemm_f32_wk: "gemm_wk", L.conv8_f32_wk: "conv",
                 L.gemm_f32_rmsprop: "gemm_rms", L.gemm_f32_rmsprop_multi: "rms_multi", L.gemm_f32_wk_multi: "wk_multi",
                 # (the same launch also carrying the step's column sums / small updates in a few extra workgroups)
                 L.gemm_f32_rmsprop_multi_colsum: "rms_multi", L.gemm_f32_rmsprop_multi_end: "rms_multi"}
@@ -333,15 +333,24 @@ def main():
                          device=device, seed=99 + rank)
         bs.capture()
         labels = (torch.arange(chunk, device=device) % args.classes).to(torch.int32)
-        for _ in range(2):
-            bs.run_chunk(labels)
-        barrier()
-        t1 = time.perf_counter()
         nchunks = 4
-        for _ in range(nchunks):
-            bs.run_chunk(labels)
-        barrier()
-        sdt = parallel.max_over_ranks(time.perf_counter() - t1, device)
+
+        def timed_chunks(sampler, blocks=5):
+            """median time of `blocks` blocks of nchunks chunks (a block is ~15 ms: one block alone sits on whatever the
+            clocks are doing after the capture; the first run of this measured 6.0 M where every other gave 9.2 M)"""
+            for _ in range(4):
+                sampler.run_chunk(labels)
+            ts = []
+            for _ in range(blocks):
+                barrier()
+                t = time.perf_counter()
+                for _ in range(nchunks):
+                    sampler.run_chunk(labels)
+                barrier()
+                ts.append(parallel.max_over_ranks(time.perf_counter() - t, device))
+            return float(np.median(ts))
+
+        sdt = timed_chunks(bs)
         G_MAC = (args.latent_dim + args.classes) * 512 + 512 * 1024 + 1024 * 2048 + 2048 * args.seq_len   # SURVEY 8: per trace
         tps = world * nchunks * chunk / sdt
         samp = dict(value=tps, unit="traces/s", chunk=chunk, operands="f32",
@@ -382,27 +391,12 @@ def main():
         bs16 = BulkSampler(eng.generator_state(), args.seq_len, args.classes, args.latent_dim, dmin, dmax, chunk=chunk,
                            device=device, seed=99 + rank, operands="bf16")
         bs16.capture()
-        for _ in range(2):
-            bs16.run_chunk(labels)
-        barrier()
-        t1 = time.perf_counter()
-        for _ in range(nchunks):
-            bs16.run_chunk(labels)
-        barrier()
-        sdt16 = parallel.max_over_ranks(time.perf_counter() - t1, device)
-        samp["bf16_operands_traces_per_s"] = world * nchunks * chunk / sdt16
+        samp["bf16_operands_traces_per_s"] = world * nchunks * chunk / timed_chunks(bs16)
         # and with split-bf16 contractions over the fp32 weights (products ~1e-5 relative)
         bs3 = BulkSampler(eng.generator_state(), args.seq_len, args.classes, args.latent_dim, dmin, dmax, chunk=chunk,
                           device=device, seed=99 + rank, operands="bf16x3")
         bs3.capture()
-        for _ in range(2):
-            bs3.run_chunk(labels)
-        barrier()
-        t1 = time.perf_counter()
-        for _ in range(nchunks):
-            bs3.run_chunk(labels)
-        barrier()
-        samp["bf16x3_operands_traces_per_s"] = world * nchunks * chunk / parallel.max_over_ranks(time.perf_counter() - t1, device)
+        samp["bf16x3_operands_traces_per_s"] = world * nchunks * chunk / timed_chunks(bs3)
 
     # roofline of the contraction core in the mode that ran: f32-input MFMA 157.3 TF; bf16 MFMA 2.5 PF dense, of which
     # the split-bf16 mode spends three instructions per product term (peak / 3 in fp32-equivalent FLOP)
