@@ -200,6 +200,41 @@ def cpu_baseline(args, seconds=20.0):
                 sample=f"{n} iterations of the same config-2 step (B={B}, S={S}) on {threads} host threads")
 
 
+def self_launch(n: int) -> int:
+    """`python bench.py --gpus N` without a torchrun environment: start N fresh rank processes of this same command line
+    (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* set as torch.distributed.run would), relay their output and return the first
+    non-zero exit code.  Called BEFORE this process makes any GPU call (torch.cuda.device_count() does not initialise the
+    device on this stack) -- the children are new processes, never a re-exec of one that touched the GPU.  The reference
+    has no launcher to mirror: src/mlp_df_wgan_train.py:98-100 picks one device."""
+    import socket
+    import subprocess
+    have = torch.cuda.device_count()
+    shared = os.environ.get("WFD_DIST_BACKEND") == "gloo"        # test rig: gloo ranks may share a GPU (never a measurement)
+    if have < 1 or (have < n and not shared):
+        print(f"bench.py: --gpus {n} but {have} HIP device(s) visible; refusing to run fewer ranks than asked for "
+              "(WFD_DIST_BACKEND=gloo lets test ranks share a GPU)", file=sys.stderr)
+        return 2
+    with socket.socket() as s:                                    # a free rendezvous port
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0",
+                   WFD_BENCH_LAUNCHER="self")
+        procs.append(subprocess.Popen([sys.executable, "-u", os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                      stdout=subprocess.PIPE if r == 0 else None))
+    out0, _ = procs[0].communicate()            # rank 0 prints the ONE JSON line; the others print nothing on stdout
+    rcs = [procs[0].returncode] + [p.wait() for p in procs[1:]]
+    sys.stdout.write(out0.decode())
+    sys.stdout.flush()
+    bad = [(r, c) for r, c in enumerate(rcs) if c != 0]
+    if bad:
+        print(f"bench.py: rank exit codes {bad}", file=sys.stderr)
+        return next(c for _, c in bad) or 1
+    return 0
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -243,10 +278,17 @@ def main():
     ap.add_argument("--cpu-seconds", type=float, default=20.0)
     args = ap.parse_args()
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # launched plainly (the shape of the driver's 1-GPU command): start the N ranks ourselves, before any GPU call
+        raise SystemExit(self_launch(args.gpus))
+
     from wfd_gan_amd import parallel
     rank, world, local = parallel.init_from_env()
-    if world != args.gpus and world > 1:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with --nproc-per-node {args.gpus}, or plainly "
+                         f"(python bench.py --gpus {args.gpus}) and bench.py starts the ranks itself")
+    if world > 1 and os.environ.get("WFD_DIST_BACKEND") != "gloo" and torch.cuda.device_count() < world:
+        raise SystemExit(f"--gpus {world} but {torch.cuda.device_count()} HIP device(s) visible")
     if os.environ.get("WFD_DIST_BACKEND") == "gloo" and local >= torch.cuda.device_count():
         local %= torch.cuda.device_count()          # test rig: several gloo ranks sharing one GPU (never a measurement)
     device = torch.device(f"cuda:{local}")
@@ -441,6 +483,9 @@ def main():
             "metric": "WGAN train iterations/s (100-class, L=1400, fp32; one iteration = loop body on one 64-row batch: "
                       "D-step every iteration, G-step every 3rd; N GPUs weak-scaled = N such batches per optimizer step)",
             "value": its * 1.0, "unit": "iterations/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ranks_in_collective": torch.distributed.get_world_size() if torch.distributed.is_initialized() else 1,
+            "dist_backend": torch.distributed.get_backend() if torch.distributed.is_initialized() else None,
+            "launcher": os.environ.get("WFD_BENCH_LAUNCHER", "torchrun" if "TORCHELASTIC_RUN_ID" in os.environ else "plain"),
             "ms_per_step": ms_per_step, "timed_blocks": len(dts), "block_stat": "mean" if ragged else "median",
             "block_ms": [round(x * 1e3, 3) for x in dts],
             "higher_is_better": True, "scaling": "strong" if (args.dp == "strong" and world > 1) else "weak",
@@ -472,13 +517,9 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args, args.cpu_seconds)
         print(json.dumps(out), flush=True)
-    if torch.distributed.is_initialized():
-        # the engines (and their HIP graphs with captured RCCL nodes) go before the communicator does
-        import gc
-        del drv, eng
-        gc.collect()
-        torch.cuda.synchronize()
-        torch.distributed.destroy_process_group()
+    # the engines (and their HIP graphs with captured RCCL nodes) go before the communicator does
+    del drv, eng
+    parallel.shutdown(destroy=True)
 
 
 if __name__ == "__main__":

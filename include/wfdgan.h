@@ -461,7 +461,9 @@ int wfd_colsum_tall(const float* X, int ld, int M, int N, int rows_per_chunk, fl
  * process ends); the call allocates nothing.  Returns 3 when ceil(M / rows_per_chunk) * N exceeds that size (use
  * wfd_colsum_tall with a workspace then).  Same kernels, same summation order, bit-identical results.  All calls on one
  * GPU share the array: calls that overlap on one GPU (different streams) race -- serialise them.  The first call on a
- * device looks the array's address up (hipGetSymbolAddress): make it outside stream capture. */
+ * device looks the array's address up (hipGetSymbolAddress): make it outside stream capture.  Every GPU has its own copy
+ * of the array: a non-null `stream` must belong to the CURRENT device (hipSetDevice first); a stream of another device is
+ * rejected with code 1 instead of handing its kernels the wrong GPU's array. */
 int wfd_colsum_tall_static(const float* X, int ld, int M, int N, int rows_per_chunk, float* out, void* stream);
 int wfd_static_scratch_floats(void);
 /* weight gradient of the first conv (Cin = 1): dW[co][t] = sum_{b,l} dZ[b][l][co] * x[b][l+t-3], x[b][l] = X[b*ldx+xoff+l];

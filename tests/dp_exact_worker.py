@@ -93,8 +93,9 @@ def trainer_worker(rank, world, port, argv, q):
         import torch.distributed as dist
         from wfd_gan_amd import mlp_df_wgan_train
         out = mlp_df_wgan_train.main(argv)
-        dist.barrier()
-        dist.destroy_process_group()
+        # main() ends with parallel.shutdown(): barrier (ranks != 0 outlive rank 0's writes) -> engines released ->
+        # synchronize -> destroy_process_group, because it created the group itself
+        assert not dist.is_initialized(), "the trainer left its process group behind"
         q.put((rank, out, None))
     except BaseException as e:  # noqa: BLE001
         import traceback
@@ -184,8 +185,7 @@ def generate_worker(rank, world, port, mdir, outp, n, q):
     try:
         from wfd_gan_amd import generate
         generate.main(["-m", mdir, "--n", str(n), "--chunk", "64", "--seed", "3", "--out", outp])
-        if torch.distributed.is_initialized():
-            torch.distributed.destroy_process_group()
+        assert not torch.distributed.is_initialized(), "generate.main() left its process group behind"
     except Exception as e:          # noqa: BLE001
         msgs.append(f"rank {rank}: {type(e).__name__}: {e}")
     q.put((rank, msgs))

@@ -87,3 +87,20 @@ def test_gradient_allreduce_world2_gloo():
         assert ok, f"rank {rank}: all-reduced gradient != mean of per-rank gradients"
         assert tmax == 2.0 and tsum == 2.0
         assert t == [0.0, 0.0, 0.0]
+
+
+def test_bench_plain_multi_gpu_launch_is_refused_without_devices():
+    """bench.py --gpus 2 with no torchrun environment starts its own ranks -- or, with fewer HIP devices than ranks (none in
+    the build container), exits non-zero with a clear message instead of silently running one (VERDICT r2 #1)."""
+    import os
+    import subprocess
+    import sys
+    import torch
+    if torch.cuda.device_count() >= 2:
+        import pytest
+        pytest.skip("enough devices: the launch would run")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "WFD_DIST_BACKEND")}
+    p = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "0"],
+                       env=env, cwd=root, capture_output=True, text=True, timeout=120)
+    assert p.returncode != 0 and "refusing to run fewer ranks" in p.stderr and not p.stdout.strip()

@@ -165,6 +165,39 @@ def test_bench_two_ranks_share_one_gpu(mode):
     assert not [ln for ln in outs[1][0].splitlines() if ln.startswith("{")]          # only rank 0 prints
 
 
+def test_bench_plain_launch_starts_its_own_ranks():
+    """`python bench.py --gpus 2` with NO torchrun environment (the shape of the driver's 1-GPU command): bench.py starts
+    the two ranks itself before any GPU call, relays rank 0's line and reports what the collective saw.  Both ranks share
+    cuda:0 over gloo here (WFD_DIST_BACKEND=gloo; one GPU on the test box)."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env["WFD_DIST_BACKEND"] = "gloo"
+    p = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "6", "--warmup", "3",
+                        "--inst", "20", "--no-sampling", "--no-cpu-baseline"], env=env, cwd=root, capture_output=True,
+                       text=True, timeout=280)
+    assert p.returncode == 0, p.stderr[-3000:]
+    lines = [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1                                   # ONE JSON line for the whole job
+    res = json.loads(lines[0])
+    assert res["n_gpus"] == 2 and res["ranks_in_collective"] == 2 and res["dist_backend"] == "gloo"
+    assert res["launcher"] == "self" and res["scaling"] == "weak" and res["config"]["global_batch"] == 128
+    # a wrong --gpus under a torchrun-style environment is refused, never silently run on fewer ranks
+    env2 = dict(env, RANK="0", WORLD_SIZE="1", LOCAL_RANK="0")
+    p2 = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "0"],
+                        env=env2, cwd=root, capture_output=True, text=True, timeout=120)
+    assert p2.returncode != 0 and "WORLD_SIZE=1" in p2.stderr
+    # more ranks than devices on the real backend: refused with a clear message before anything runs
+    env3 = {k: v for k, v in env.items() if k != "WFD_DIST_BACKEND"}
+    n = torch.cuda.device_count() + 1
+    p3 = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", str(n), "--steps", "3", "--warmup", "0"],
+                        env=env3, cwd=root, capture_output=True, text=True, timeout=120)
+    assert p3.returncode != 0 and "refusing to run fewer ranks" in p3.stderr and not p3.stdout.strip()
+
+
 @pytest.mark.parametrize("world", [2, 3])
 def test_generate_cli_shards_the_label_list(world, tmp_path):
     """generate.py under torchrun (src/generate.py's sample() in bulk, SURVEY.md 8e: embarrassingly parallel, no collective):

@@ -198,6 +198,84 @@ def _data_parallel_world1_nccl(captured, monkeypatch):
             assert torch.equal(a, b)
 
 
+def test_capture_fallback_drops_stale_collective_handles(monkeypatch, nccl_world1):
+    """A capture WITH collectives that fails half-way (here: forced, in the finish() of the first captured D-step, after the
+    three buckets' start() calls ran under the capture) must fall back to eager collectives between graph stages -- and the
+    Work handles created under the abandoned capture must be gone, or the eager retry's first finish() waits on them
+    (ADVICE r2).  The fallback engine then has to reproduce the single-rank engine bit for bit."""
+    import gc
+    import warnings
+    from wfd_gan_amd import parallel
+    from wfd_gan_amd.engine import TrainEngine
+    monkeypatch.setenv("WFD_DP_GRAPH", "1")
+    S, C, Z, B = 41, 5, 16, 8
+    st, e1, Xs, y = _setup(S, C, Z, B, "div")
+    e2 = TrainEngine(S, C, Z, B, e1.scaler_min, e1.scaler_max, e1.generator_state(), e1.discriminator_state(),
+                     {k: v for k, v in st.DF.items()}, device=DEV, world_size=1, force_sync=True)
+    for e in (e1, e2):
+        e.attach_dataset(torch.from_numpy(Xs), torch.from_numpy(y), shuffle_seed=5)
+    e1.capture_graphs()
+    real_finish, seen = parallel.GradSync.finish, {"forced": 0, "stale": None}
+
+    def finish(self):
+        if torch.cuda.is_current_stream_capturing() and not seen["forced"]:
+            seen["forced"] = 1
+            seen["stale"] = len(self.pending)
+            raise RuntimeError("forced capture failure (test)")
+        return real_finish(self)
+    monkeypatch.setattr(parallel.GradSync, "finish", finish)
+    with warnings.catch_warnings(record=True) as w:
+        warnings.simplefilter("always")
+        e2.capture_graphs()
+    assert seen["forced"] == 1 and seen["stale"] == 3          # three buckets were in flight when the capture died
+    assert any("falling back to eager collectives" in str(x.message) for x in w)
+    assert e2._gsync.pending == []
+    assert len(e2.graph_d) == 7                                # stage, start, stage, start, stage, start+finish, stage
+    for i in range(7):
+        e1.iteration(i)
+        e2.iteration(i)
+    torch.cuda.synchronize()
+    assert torch.equal(e1.Dp.flat, e2.Dp.flat) and torch.equal(e1.Gp.flat, e2.Gp.flat)
+    assert e1.d_stats() == e2.d_stats()
+    del e1, e2
+    gc.collect()
+    torch.cuda.synchronize()
+
+
+def test_trainer_world1_nccl_exits_cleanly(tmp_path):
+    """The trainer CLI as a 1-rank torchrun-style launch on the real "nccl" (RCCL) backend, in a process of its own: the
+    collectives are captured inside the step graphs, rank 0 writes the artefacts, and main() ends with the ordered
+    shutdown (engines released before destroy_process_group) -- exit code 0, no abort at interpreter teardown."""
+    import subprocess
+    import sys
+    n_cls, n_inst, L = 5, 21, 40
+    X, y = O.synth_dataset(n_cls, n_inst, L, 4, 13, 122, seed=0)
+    ddir = tmp_path / "ds" / "feature"
+    ddir.mkdir(parents=True)
+    npz = str(ddir / "raw_feature_synth.npz")
+    np.savez(npz, features=X, labels=y)
+    torch.manual_seed(0)
+    ck = str(tmp_path / "df.ckpt")
+    torch.save(O.make_df_state(L, n_cls), ck)
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = ("import os, sys, torch.distributed as dist\n"
+            "from wfd_gan_amd import mlp_df_wgan_train as T, parallel\n"
+            "dist.init_process_group('nccl', rank=0, world_size=1)\n"
+            "parallel._OWN_PG = True\n"
+            "out = T.main(sys.argv[1:])\n"
+            "assert not dist.is_initialized()\n"
+            "print('OUT', out)\n")
+    env = dict(os.environ, RANK="0", WORLD_SIZE="1", LOCAL_RANK="0", MASTER_ADDR="127.0.0.1", MASTER_PORT="29537",
+               HSA_ENABLE_IPC_MODE_LEGACY="0", WFD_FORCE_DP="1")
+    p = subprocess.run([sys.executable, "-c", code, "-d", npz, "--f_model", ck, "--n_epochs", "2", "--batch_size", "16",
+                        "--latent_dim", "24", "--seed", "7", "--freq", "2", "--dp", "weak"], env=env, cwd=root,
+                       capture_output=True, text=True, timeout=280)
+    assert p.returncode == 0, p.stderr[-3000:]
+    out = [ln for ln in p.stdout.splitlines() if ln.startswith("OUT ")][-1][4:]
+    assert os.path.isfile(os.path.join(out, "model", "discriminator.ckpt"))
+    assert os.path.isfile(os.path.join(out, "checkpoint", "loss.npz"))
+
+
 def test_trainer_and_sampler_cli(tmp_path):
     from wfd_gan_amd import generate, mlp_df_wgan_train
     n_cls, n_inst, L = 5, 21, 40           # 105 rows, batch 16 -> 6 full batches + ragged tail of 9

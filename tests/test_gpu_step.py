@@ -83,8 +83,10 @@ def exact_params(sd, specs):
 @pytest.mark.parametrize("name", ["tiny", "cfg1", "cfg2", "cfg4a", "cfg4b"])
 def test_iterations_match_reference_fixture(name):
     """cfg4a / cfg4b are BASELINE config-4 shapes (B = 256 at L = 2500; B = 128 at L = 5000, DF FC-in 512,
-    src/model.py:208-212): the step then runs the tall BatchNorm kernels, K-split weight gradients and the single-split
-    fused products that the B = 64 step never selects."""
+    src/model.py:208-212): the step then runs the column-per-thread BatchNorm kernel (129..512 rows), weight gradients into
+    gradient buffers where the contraction is K-split, and the single-split fused products that the B = 64 step never
+    selects.  The kernels of more than 512 rows (bn_tallf_*, bn_bwd_tall, colsum_tall, gemm_f32_nt128_kernel) are NOT
+    reached by these fixtures: test_large_batch_step_exact_on_own_parameters below runs them."""
     from oracle import wfdgan_oracle as O
     torch.set_num_threads(8)
     fx, meta = load_iter_fixture(name)
@@ -268,6 +270,137 @@ def own_step(g, sq_before, lr):
     g = g.detach().double()
     sq = 0.99 * sq_before + 0.01 * g * g
     return -lr * g / (sq.sqrt() + 1e-8)
+
+
+@pytest.mark.parametrize("B", [1024, 4096])
+def test_large_batch_step_exact_on_own_parameters(B):
+    """BASELINE config 4 at L = 1400 (src/model.py:20-34,208-212 shapes; loop body src/mlp_df_wgan_train.py:182-275): ONE
+    whole iteration (D-step + G-step) at B = 1024 and B = 4096 against the oracle in fp64 on the same seeded inputs and the
+    same initial parameters -- the shapes DESIGN section 6 quotes 0.59-0.68 of the f32 MFMA peak for.  No fixture: the
+    oracle (pinned against the reference by tests/golden/make_golden.py) IS the checker, as in
+    test_iterations_exact_on_own_parameters.  f32 operands: every scalar, row and gradient element at that test's
+    tolerances; bf16x3 operands: the loss scalars / rows at north_star's 1e-3 (per-row penalty 1e-2, as stated in
+    test_first_iteration_split_bf16_operands).  The test first asserts that the large-batch branches are the ones that run."""
+    from oracle import wfdgan_oracle as O
+    from wfd_gan_amd.engine import TrainEngine
+    from wfd_gan_amd.plan import NT
+    torch.set_num_threads(16)
+    S, C, Z = 1401, 100, 500
+    X, y = O.synth_dataset(C, B // C + 2, S - 1, 50, 75, 179, seed=3)
+    dmin, dmax = X.min(0), X.max(0)
+    scale, min_ = O.scaler_params(dmin, dmax)
+    Xs = X * scale + min_
+    perm = np.random.RandomState(5).permutation(Xs.shape[0])[:B]
+    traces, labels = Xs[perm].astype(np.float32), y[perm].copy()
+    g = torch.Generator().manual_seed(B)
+    z = torch.randn(B, Z, generator=g)
+    mk = lambda: [(torch.rand(B, n, generator=g) > 0.2).float() * 1.25 for n in (2048, 1024, 512)]
+    mr, mf, mg = mk(), mk(), mk()
+    st = O.make_state(S, C, Z, dmin[0], dmax[0], seed=1, df_seed=2)
+    O.perturb_df_bn(st.DF, 4)
+    with torch.no_grad():
+        st.D["model.9.bias"] += 0.05          # some, not all, generated rows selected for the observer term
+    meta = dict(seq_len=S, class_dim=C, latent_dim=Z, scaler_min=float(dmin[0]), scaler_max=float(dmax[0]), lr=2e-4,
+                alpha=0.02, n_critic=3)
+
+    def engine(operands):
+        return TrainEngine(S, C, Z, B, dmin[0], dmax[0], {k: v.detach() for k, v in st.G.items()},
+                           {k: v.detach() for k, v in st.D.items()}, st.DF, operands=operands, fuse_opt=True)
+
+    eng = engine("f32")
+    L = eng.L
+    # -- which branches this batch size selects (VERDICT r2: never run inside a tested step before) ----------------------
+    assert not eng.fuse_d and (not eng.fuse_g) == (B >= 1024)      # optimizer-in-store only below 1024 contraction rows
+    fns_d = [c[0] for c in eng.plan_d.calls]
+    fns_g = [c[0] for c in eng.plan_g.calls]
+    assert L.colsum_tall in fns_g and L.bn_bwd_tall in fns_g                         # engine.py: B > 512
+    bn_rows = [c[1][4] for c in eng.plan_d.calls if c[0] is L.bn_train_relu]
+    assert bn_rows == [B, B] and B > 512                                             # epilogues.hip: bn_tallf_* from 513 rows
+    nt128 = [c for c in eng.plan_d.calls + eng.plan_g.calls
+             if (c[0] is L.gemm_f32 and c[1][0] == NT and c[1][8] >= 1024 and c[1][11] == 1)
+             or (c[0] is L.gemm_f32_fused and c[1][0] == NT and c[1][7] >= 1024)]
+    assert len(nt128) >= 6                                                           # gemm.hip use_nt128: M >= 1024, one split
+    assert L.rmsprop in fns_d                                                        # flat optimizer pass, gradient buffers
+
+    own = state_from_engine_(eng, meta, st.DF)
+    tr, lb = torch.from_numpy(traces), torch.from_numpy(labels)
+    eng.set_batch(tr, lb, z)
+    eng.set_masks([torch.cat([a, b]) for a, b in zip(mr, mf)], mg)
+    d_before = {n: eng.Dp.p[n].double().cpu() for n, _ in eng.Dp.specs}
+    eng.d_step()
+    torch.cuda.synchronize()
+    eng.check_length_index()
+    d_grads = {n: eng.Dp.g[n].double().cpu() for n, _ in eng.Dp.specs}
+    d_after = {n: eng.Dp.p[n].double().cpu() for n, _ in eng.Dp.specs}
+    s = eng.d_stats()
+    pen_rows = eng.buf["PEN"][:2 * B].double().cpu()
+    fake = eng.fake_rows[:, :S].double().cpu()
+    idx = eng.buf["idx"].cpu().numpy()
+    g_before = {n: eng.Gp.p[n].double().cpu() for n, _ in eng.Gp.specs}
+    eng.g_step()
+    torch.cuda.synchronize()
+    m64 = lambda ms: [t.double() for t in ms]
+    x = O.iteration(own, tr.double(), lb, z.double(), True, m64(mr), m64(mf), m64(mg), keep=True,
+                    after_d_step=lambda o: [o.D[n].data.copy_(d_after[n]) for n in d_after])
+    w = f"B={B} f32"
+    assert np.array_equal(idx, x["idx_d"].numpy()), f"{w} idx"
+    _frac_check(fake, x["fake_d"], f"{w} fake rows", max_out_frac=0.0)
+    _frac_check(pen_rows, torch.cat([x["n_r"], x["n_f"]]), f"{w} per-row penalty", max_out_frac=8.0 / (2 * B))
+    for k, atol in (("penalty", 0.0), ("mean_rv", 2e-5), ("mean_fv", 2e-5), ("d_loss", 4e-5), ("w_dist", 4e-5)):
+        close(s[k], x[k], atol=atol, what=f"{w} {k}")
+    gmax = max(float(t.abs().max()) for t in x["d_grads"])
+    zero_sq = {n: torch.zeros_like(d_before[n]) for n in d_before}
+    for (n, _), want in zip(eng.Dp.specs, x["d_grads"]):
+        _grad_check(d_grads[n], want, f"{w} D grad {n}", floor=1e-7 * gmax)
+        _frac_check(d_after[n] - d_before[n], own_step(d_grads[n], zero_sq[n], 2e-4), f"{w} D update {n}", rtol=1e-4,
+                    max_out_frac=0.0, floor=1e-8)
+    gs = eng.g_stats()
+    assert 0 < x["n_sel"] and gs["n_sel"] == x["n_sel"], f"{w} n_sel {gs['n_sel']} vs {x['n_sel']}"
+    for k, atol in (("g_loss", 2e-5), ("f_loss", 2e-5), ("g_combined", 4e-5)):
+        close(gs[k], x[k], atol=atol, what=f"{w} {k}")
+    gmax = max(float(t.abs().max()) for t in x["g_grads"])
+    for (n, _), want in zip(eng.Gp.specs, x["g_grads"]):
+        _grad_check(eng.Gp.g[n], want, f"{w} G grad {n}", floor=1e-6 * gmax)
+        _frac_check(eng.Gp.p[n].double().cpu() - g_before[n], own_step(eng.Gp.g[n].double().cpu(), torch.zeros_like(g_before[n]), 2e-4),
+                    f"{w} G update {n}", rtol=1e-4, max_out_frac=0.0, floor=1e-8)
+    bn = torch.cat([eng.Gbuf[f"model.{i}.{q}"] for i in (3, 6) for q in ("running_mean", "running_var")]).double().cpu()
+    bn64 = torch.cat([own.G[f"model.{i}.{q}"] for i in (3, 6) for q in ("running_mean", "running_var")])
+    _frac_check(bn, bn64, f"{w} BN running statistics", max_out_frac=0.0)
+    del eng
+    torch.cuda.empty_cache()
+
+    # -- the same iteration with split-bf16 contractions (the mode the large-batch sweep's middle column measures) --------
+    e3 = engine("bf16x3")
+    e3.set_batch(tr, lb, z)
+    e3.set_masks([torch.cat([a, b]) for a, b in zip(mr, mf)], mg)
+    e3.d_step()
+    torch.cuda.synchronize()
+    assert e3.L.get_gemm_mode() == 0
+    w = f"B={B} bf16x3"
+    s3 = e3.d_stats()
+    idx_ok = e3.buf["idx"].cpu().numpy() == x["idx_d"].numpy()
+    assert (~idx_ok).sum() <= max(1, B // 1024), f"{w} idx: {(~idx_ok).sum()} rows off"
+    rows = torch.from_numpy(np.concatenate([np.ones(B, bool), idx_ok]))          # fake rows whose length index agrees
+    _frac_check(e3.buf["PEN"][:2 * B].double().cpu()[rows], torch.cat([x["n_r"], x["n_f"]])[rows], f"{w} per-row penalty",
+                rtol=1e-2, max_out_frac=8.0 / (2 * B))
+    _frac_check(e3.fake_rows[:, :S].double().cpu()[torch.from_numpy(idx_ok)], x["fake_d"][torch.from_numpy(idx_ok)],
+                f"{w} fake rows", max_out_frac=0.0)
+    for k, atol in (("penalty", 0.0), ("mean_rv", 2e-5), ("mean_fv", 2e-5), ("d_loss", 4e-5), ("w_dist", 4e-5)):
+        close(s3[k], x[k], atol=atol + (1e-3 * abs(float(x[k])) if not idx_ok.all() else 0.0), what=f"{w} {k}")
+    dn = np.array([float((e3.Dp.p[n].double().cpu() - d_before[n]).norm()) for n, _ in e3.Dp.specs])
+    dn64 = np.array([float((d_after[n] - d_before[n]).norm()) for n, _ in e3.Dp.specs])
+    assert rel_err(dn, dn64) < 1e-2, f"{w} critic update norms {dn} vs {dn64}"
+    e3.g_step()
+    torch.cuda.synchronize()
+    g3 = e3.g_stats()
+    assert abs(g3["n_sel"] - x["n_sel"]) <= max(2, B // 512), f"{w} n_sel {g3['n_sel']} vs {x['n_sel']}"
+    close(g3["g_loss"], x["g_loss"], atol=2e-4, what=f"{w} g_loss")
+    close(g3["f_loss"], x["f_loss"], rtol=5e-3, atol=2e-4, what=f"{w} f_loss")
+
+
+def state_from_engine_(eng, meta, df_state):
+    from tests.util import state_from_engine
+    return state_from_engine(eng, meta, df_state)
 
 
 @pytest.mark.parametrize("name", ["cfg1", "cfg2", "cfg4a", "cfg4b"])

@@ -120,6 +120,31 @@ def test_df_forward_train_mode_matches_oracle():
     assert (m(x.to(DEV)).cpu() - want_eval).abs().max().item() < 1e-4 * max(1.0, want_eval.abs().max().item())
 
 
+def test_df_eval_after_train_forward_sees_the_new_running_statistics():
+    """eval, train, eval with the SAME batch size and no refresh(): the train-mode forward updates the BatchNorm running
+    statistics in place, so the packed eval-mode observer cached by the first eval forward is stale and must be rebuilt
+    (the cache key (B, fc.weight storage, device) does not change).  The last eval is compared with the oracle on
+    the module's state after the train forward, and must differ from the first eval."""
+    length, C, B = 64, 5, 16
+    m, sd = _df(length, C, seed=13)
+    m.to(DEV).eval()
+    g = torch.Generator().manual_seed(9)
+    x = torch.rand(B, 1, length, generator=g)
+    first = m(x.to(DEV)).cpu()
+    with torch.no_grad():
+        want_first = O.df_forward(sd, x)
+    assert (first - want_first).abs().max().item() < 1e-4 * max(1.0, want_first.abs().max().item())
+    m.train()
+    m(x.to(DEV) * 3.0 + 1.0)                       # moves every running mean / variance
+    m.eval()
+    last = m(x.to(DEV)).cpu()
+    sd2 = {k: v.cpu() for k, v in m.state_dict().items()}
+    with torch.no_grad():
+        want_last = O.df_forward(sd2, x)
+    assert (last - want_last).abs().max().item() < 1e-4 * max(1.0, want_last.abs().max().item())
+    assert (last - first).abs().max().item() > 1e-3          # the statistics did change the logits
+
+
 def test_sampler_raises_where_reference_raises():
     """A saturated length output (sigmoid -> 1.0, index = seq_size) makes the reference's Generator.forward raise IndexError
     (src/model.py:44); the bulk sampler reports it the same way instead of returning clamped traces."""

@@ -14,6 +14,21 @@
         if (e__ != hipSuccess) return WFD_ERR_LAUNCH; \
     } while (0)
 
+// Raise a kernel's dynamic-LDS limit once PER DEVICE (a `static bool` would serve only the first GPU a process uses; the
+// bitmask is also safe against concurrent host threads).  `fn` is the kernel in parentheses: WFD_LDS_ATTR((k<A, B>), bytes).
+#include <atomic>
+#define WFD_LDS_ATTR(fn, bytes)                                                                                          \
+    do {                                                                                                                  \
+        static std::atomic<unsigned long long> done__{0};                                                                 \
+        int dev__ = 0;                                                                                                    \
+        (void)hipGetDevice(&dev__);                                                                                       \
+        const unsigned long long bit__ = 1ull << (dev__ & 63);                                                            \
+        if (!(done__.load(std::memory_order_acquire) & bit__)) {                                                          \
+            (void)hipFuncSetAttribute((const void*)fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(bytes));         \
+            done__.fetch_or(bit__, std::memory_order_release);                                                            \
+        }                                                                                                                 \
+    } while (0)
+
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 

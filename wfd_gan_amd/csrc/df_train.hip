@@ -377,6 +377,14 @@ int wfd_colsum_tall_static(const float* X, int ld, int M, int N, int rows_per_ch
     if (!X || !out || M <= 0 || N <= 0 || rows_per_chunk <= 0 || ld < N) return WFD_ERR_ARG;
     const long need = (long)cdiv(M, rows_per_chunk) * N;
     if (need > SCRATCH_FLOATS) return WFD_ERR_WORKSPACE;          // beyond the static array: use wfd_colsum_tall
+    // `scratch` exists once per GPU: the kernels must run on the device whose copy is handed to them.  A non-null stream
+    // names its device; it has to be the current one (the null stream always is).
+    if (stream) {
+        int cur = -1;
+        hipDevice_t sdev = -1;
+        if (hipGetDevice(&cur) != hipSuccess || hipStreamGetDevice((hipStream_t)stream, &sdev) != hipSuccess) return WFD_ERR_LAUNCH;
+        if ((int)sdev != cur) return WFD_ERR_ARG;
+    }
     float* part = nullptr;
     const int rc = scratch_of_current_device(&part);
     if (rc != WFD_OK) return rc;

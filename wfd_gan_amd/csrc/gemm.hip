@@ -594,12 +594,8 @@ inline int conv8_c32_cpw(int nchunks, int gy) {
 
 template <bool EPI>
 int launch_conv8_c32(const GemmArgs& g, hipStream_t st) {
-    static bool attr = false;
     const size_t lds = (size_t)C32_LDS_FLOATS * sizeof(float);
-    if (!attr) {
-        (void)hipFuncSetAttribute((const void*)conv8_c32_kernel<EPI>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        attr = true;
-    }
+    WFD_LDS_ATTR((conv8_c32_kernel<EPI>), lds);
     const int nchunks = cdiv(g.M + ((EPI && g.pool_out) ? 3 : 0), C32_ROWS), gy = cdiv(g.N, 32), cpw = conv8_c32_cpw(nchunks, gy);
     hipLaunchKernelGGL((conv8_c32_kernel<EPI>), dim3(cdiv(nchunks, cpw), gy), dim3(NTHREADS), lds, st, g, cpw, nchunks);
     WFD_CHECK_LAUNCH();
@@ -751,21 +747,12 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_f32_nt128_kernel(GemmArgs g,
 
 template <bool EPI>
 int launch_nt128(const GemmArgs& g, hipStream_t st) {
-    static bool attr = false;
     const size_t lds = (size_t)4 * T128_F * sizeof(float);
-    if (!attr) {
-        (void)hipFuncSetAttribute((const void*)gemm_f32_nt128_kernel<EPI>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        attr = true;
-    }
+    WFD_LDS_ATTR((gemm_f32_nt128_kernel<EPI>), lds);
     const int gx = cdiv(g.N, T128), gy = cdiv(g.M, T128);
     static const int pf2 = getenv("WFD_NT128_PF2") ? atoi(getenv("WFD_NT128_PF2")) : 1;        // (the switch: same-session A/B)
     if (pf2 && g.K % BK == 0 && g.K >= 3 * BK) {
-        static bool attr2 = false;
-        if (!attr2) {
-            (void)hipFuncSetAttribute((const void*)gemm_f32_nt128_kernel<EPI, true>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                      (int)lds);
-            attr2 = true;
-        }
+        WFD_LDS_ATTR((gemm_f32_nt128_kernel<EPI, true>), lds);
         hipLaunchKernelGGL((gemm_f32_nt128_kernel<EPI, true>), dim3(gx * gy), dim3(NTHREADS), lds, st, g, gx, gy);
         WFD_CHECK_LAUNCH();
         return WFD_OK;

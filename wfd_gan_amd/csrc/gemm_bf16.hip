@@ -161,12 +161,10 @@ int wfd_gemm_bf16_nt(const void* A, int lda, const void* B, int ldb, int M, int 
     const size_t lds = (size_t)4 * TILE_E * sizeof(__bf16);
     hipStream_t st = (hipStream_t)stream;
     if (O) {
-        static bool attr1 = false;
-        if (!attr1) { (void)hipFuncSetAttribute((const void*)gemm_bf16_nt_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); attr1 = true; }
+        WFD_LDS_ATTR((gemm_bf16_nt_kernel<1>), lds);
         hipLaunchKernelGGL(gemm_bf16_nt_kernel<1>, dim3(g.gx * g.gy), dim3(NTH), lds, st, g);
     } else {
-        static bool attr0 = false;
-        if (!attr0) { (void)hipFuncSetAttribute((const void*)gemm_bf16_nt_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); attr0 = true; }
+        WFD_LDS_ATTR((gemm_bf16_nt_kernel<0>), lds);
         hipLaunchKernelGGL(gemm_bf16_nt_kernel<0>, dim3(g.gx * g.gy), dim3(NTH), lds, st, g);
     }
     WFD_CHECK_LAUNCH();

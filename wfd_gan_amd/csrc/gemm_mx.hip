@@ -289,13 +289,8 @@ __global__ __launch_bounds__(XT) void gemm_mx_kernel(GemmArgs g, int kchunk, int
 template <int T, int KT, bool AKC, bool BKC, bool IM2COL, int TERMS, bool EPI>
 int mx_launch4(const GemmArgs& g, int splits, hipStream_t st) {
     using G_ = Geo<T, KT>;
-    static bool attr = false;
     const size_t lds = (size_t)2 * TERMS * ((AKC ? G_::IMG_K : G_::IMG_M) + (BKC ? G_::IMG_K : G_::IMG_M)) * sizeof(__bf16);
-    if (!attr) {
-        (void)hipFuncSetAttribute((const void*)gemm_mx_kernel<T, KT, AKC, BKC, IM2COL, TERMS, EPI>,
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        attr = true;
-    }
+    WFD_LDS_ATTR((gemm_mx_kernel<T, KT, AKC, BKC, IM2COL, TERMS, EPI>), lds);
     const int kchunk = g.ktiles_per_split * 32;       // ktiles_per_split counts 32-deep tiles (gemm.hip's BK)
     const int gx = cdiv(g.N, T), gy = cdiv(g.M, T);
     dim3 grid(gx * gy, 1, splits), block(XT);
@@ -477,12 +472,7 @@ __global__ __launch_bounds__(XT) void conv8_lds_mx_kernel(GemmArgs g, int cpw, i
 template <int CIN, int COUT, int TERMS, bool EPI>
 int cv_launch2(const GemmArgs& g, hipStream_t st) {
     using C_ = ConvGeo<CIN, COUT, TERMS>;
-    static bool attr = false;
-    if (!attr) {
-        (void)hipFuncSetAttribute((const void*)conv8_lds_mx_kernel<CIN, COUT, TERMS, EPI>,
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)C_::LDS);
-        attr = true;
-    }
+    WFD_LDS_ATTR((conv8_lds_mx_kernel<CIN, COUT, TERMS, EPI>), C_::LDS);
     const int nchunks = cdiv(g.M, CV_ROWS);
     int cpw = nchunks / 1024;                     // amortise the weight staging once the chip is covered four times over
     if (cpw < 1) cpw = 1;

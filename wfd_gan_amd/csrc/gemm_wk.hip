@@ -416,11 +416,7 @@ int launch_wk_multi(WkMulti a, hipStream_t st) {
     constexpr int LDB = BKC ? LDK : TN + 4;
     constexpr int WAVE_F = 2 * (TM * LDK + (BKC ? TN * LDK : KC * LDB));
     const size_t lds = (size_t)NW * WAVE_F * sizeof(float);
-    static bool attr = false;
-    if (!attr) {
-        (void)hipFuncSetAttribute((const void*)gemm_wk_multi_kernel<BKC, RT, CT, NW, TERMS>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        attr = true;
-    }
+    WFD_LDS_ATTR((gemm_wk_multi_kernel<BKC, RT, CT, NW, TERMS>), lds);
     long total = 0;
     for (int k = 0; k < a.n; ++k) {
         WkArgs& g = a.g[k];
@@ -450,11 +446,7 @@ int launch_wk(WkArgs g, hipStream_t st) {
     constexpr int LDB = BKC ? LDK : TN + 4;
     constexpr int WAVE_F = 2 * (TM * LDK + (BKC ? TN * LDK : KC * LDB));
     const size_t lds = (size_t)NW * WAVE_F * sizeof(float);
-    static bool attr = false;
-    if (!attr) {
-        (void)hipFuncSetAttribute((const void*)gemm_wk_kernel<BKC, IM2COL, RT, CT, NW, TERMS>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        attr = true;
-    }
+    WFD_LDS_ATTR((gemm_wk_kernel<BKC, IM2COL, RT, CT, NW, TERMS>), lds);
     g.mt = cdiv(g.M, TM);
     g.nt = cdiv(g.N, TN);
     g.cpw = cdiv(cdiv(g.K, KC), NW);

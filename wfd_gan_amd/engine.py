@@ -105,6 +105,20 @@ class FlatParams:
         return {n: self.p[n].detach().clone(memory_format=torch.contiguous_format) for n, _ in self.specs}
 
 
+def subtract_interval(ranges, lo: int, hi: int):
+    """[(begin, end)] minus [lo, hi): runs that overlap it are cut (a run containing it is split in two)."""
+    out = []
+    for a, b in ranges:
+        if b <= lo or a >= hi:
+            out.append((a, b))
+            continue
+        if a < lo:
+            out.append((a, lo))
+        if b > hi:
+            out.append((hi, b))
+    return out
+
+
 def fold_bn(sd, bn: str, lin_bias: torch.Tensor, eps: float = 1e-5):
     """eval-mode BatchNorm after a conv / linear with bias -> per-channel (scale, shift)."""
     scale = sd[f"{bn}.weight"].double() / torch.sqrt(sd[f"{bn}.running_var"].double() + eps)
@@ -665,6 +679,8 @@ class TrainEngine:
         if self._gsync is None:
             from .parallel import GradSync
             self._gsync = GradSync(self.pg)
+        if self._gsync.reset not in p.abort_hooks:
+            p.abort_hooks.append(self._gsync.reset)
         lo, hi = self.grad_buckets(which)[stage]
         fp = self.Dp if which == "D" else self.Gp
         bucket = fp.grad[lo:hi]
@@ -867,8 +883,12 @@ class TrainEngine:
                 # first layer's bias gradient + its step, the other vectors' steps, the BN running statistics: one launch
                 desc = torch.tensor([[ptr(b["GDZ1"]), 512, 0, 0, 0, 0, B, 512, ptr(G.g["model.0.bias"]), 0, 0]],
                                     dtype=torch.int64, device=self.dev)
+                # the column-sum block already applies model.0.bias's RMSprop step: take exactly its interval out of the
+                # ranges (splitting a run where it sits inside one), so that no element is updated twice or not at all
                 b0 = G.offsets["model.0.bias"]
-                flat = [v for r in G.vector_ranges() if r[0] != b0 for v in r]
+                flat = [v for r in subtract_interval(G.vector_ranges(), b0, b0 + 512) for v in r]
+                assert all(hi <= b0 or lo >= b0 + 512 for lo, hi in zip(flat[0::2], flat[1::2]))
+                assert sum(hi - lo for lo, hi in zip(flat[0::2], flat[1::2])) + 512 == sum(hi - lo for lo, hi in G.vector_ranges())
                 arr = (ctypes.c_long * len(flat))(*flat)
                 p.keep += [desc, arr]
                 st_arg = (st if fast else 0, self._rng_inc() if fast else 0, 0)
@@ -1104,6 +1124,8 @@ class TrainEngine:
             except RuntimeError:
                 if not kw:
                     raise
+                for hook in self.fast_d.abort_hooks + self.fast_g.abort_hooks:
+                    hook()
                 torch.cuda.synchronize()       # collectives refused this capture: single-step graphs only
         torch.cuda.synchronize()
         self._restore(snap)
@@ -1131,6 +1153,10 @@ class TrainEngine:
                     import warnings
                     warnings.warn("capturing the data-parallel collectives inside the step graph failed; "
                                   "falling back to eager collectives between graph stages")
+                    # Work handles created under the abandoned capture (a start() that ran before the failure) must not
+                    # be waited on by the eager retry's first finish(): drop them, then drain the device
+                    for hook in plan.abort_hooks:
+                        hook()
                     torch.cuda.synchronize()
                     return TrainEngine._capture_stages(plan, split_all=True)
                 g.keep = plan.keep          # the captured launches point into the plan's descriptor tables

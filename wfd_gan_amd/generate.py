@@ -105,6 +105,10 @@ def main(argv=None):
         path = args.out if world == 1 else args.out.replace(".npz", f".rank{rank}.npz")
         np.savez_compressed(path, traces=out.cpu().numpy(), lens=lens.cpu().numpy(), labels=labels.numpy())
     print(f"rank {rank}: sampled {b - a} traces, mean length {lens.float().mean().item():.1f}")
+    # sampling issues no collective, but the chunk graphs were captured next to a live process group: same ordered end as the
+    # trainer (sampler and graphs first, then barrier -> synchronize -> destroy_process_group)
+    del ts, out, lens
+    parallel.shutdown()
 
 
 if __name__ == "__main__":

@@ -191,7 +191,10 @@ def main(argv=None):
         parallel.broadcast_state_([t])
         seed = int(t.item())
     # single GPU: RMSprop runs inside the weight-gradient stores (engine.TrainEngine fuse_opt); data parallel keeps the flat pass
-    dp = dict(world_size=world, rank=rank, sync_bn=exact, operands=args.operands, fuse_opt=(world == 1))
+    # WFD_FORCE_DP=1: the data-parallel code path (bucketed collectives, flat optimizer pass) on a 1-rank group (test rigs)
+    force_dp = os.environ.get("WFD_FORCE_DP") == "1" and torch.distributed.is_initialized()
+    dp = dict(world_size=world, rank=rank, sync_bn=exact, operands=args.operands, fuse_opt=(world == 1 and not force_dp),
+              force_sync=force_dp)
     rng_seed = seed + 1000003 * rank
     eng = TrainEngine(seq_len, class_dim, args.latent_dim, B, scaler.data_min_[0], scaler.data_max_[0],
                       generator.state_dict(), discriminator.state_dict(), f_model.state_dict(), lr=args.lr,
@@ -294,19 +297,22 @@ def main(argv=None):
             logger.info("Early stopping since the w-dist = {}, df acc = {}.".format(w_ep, df_acc))
             break
 
-    if rank != 0:
-        return None
-    np.savez_compressed(join(checkpointdir, "loss.npz"), generator=losses["generator"],
-                        discriminator=losses["discriminator"], dist=losses["dist"])
-    torch.save({k: v.cpu() for k, v in eng.generator_state().items()},
-               join(modeldir, "generator_seqlen{}_cls{}_latentdim{}.ckpt".format(seq_len, class_dim, args.latent_dim)))
-    torch.save({k: v.cpu() for k, v in eng.discriminator_state().items()}, join(modeldir, "discriminator.ckpt"))
-    logger.info("Model saved at {}".format(modeldir))
-    joblib.dump(scaler, join(modeldir, "scaler.gz"))
-    # the same fit as plain arrays: generate.py reads this one without unpickling anything
-    np.savez(join(modeldir, "scaler.npz"), data_min=scaler.data_min_, data_max=scaler.data_max_)
-    logger.info("Scaler saved at {}".format(modeldir))
-    return pardir
+    if rank == 0:       # the write block of src/mlp_df_wgan_train.py:305-312
+        np.savez_compressed(join(checkpointdir, "loss.npz"), generator=losses["generator"],
+                            discriminator=losses["discriminator"], dist=losses["dist"])
+        torch.save({k: v.cpu() for k, v in eng.generator_state().items()},
+                   join(modeldir, "generator_seqlen{}_cls{}_latentdim{}.ckpt".format(seq_len, class_dim, args.latent_dim)))
+        torch.save({k: v.cpu() for k, v in eng.discriminator_state().items()}, join(modeldir, "discriminator.ckpt"))
+        logger.info("Model saved at {}".format(modeldir))
+        joblib.dump(scaler, join(modeldir, "scaler.gz"))
+        # the same fit as plain arrays: generate.py reads this one without unpickling anything
+        np.savez(join(modeldir, "scaler.npz"), data_min=scaler.data_min_, data_max=scaler.data_max_)
+        logger.info("Scaler saved at {}".format(modeldir))
+    # Ordered end of a data-parallel run (parallel.shutdown): the other ranks wait at the barrier until rank 0 has written;
+    # everything that holds a HIP graph with captured RCCL nodes goes BEFORE the communicator does
+    del grp, tail, eng, comm
+    parallel.shutdown()
+    return pardir if rank == 0 else None
 
 
 if __name__ == "__main__":

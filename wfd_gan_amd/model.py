@@ -301,6 +301,10 @@ class DF(nn.Module):
                     v.copy_(eng.bufs[k])
                 elif k.endswith("num_batches_tracked"):
                     v += 1
+        # the packed eval-mode observers (keyed by batch size / fc.weight storage) folded the OLD running statistics into
+        # their scale / shift: drop them, so that the next eval forward re-packs from the buffers just updated
+        for k in [k for k in self._cache if k[0] != "train"]:
+            del self._cache[k]
         return logits
 
     def forward(self, x):

@@ -11,8 +11,12 @@ import torch
 import torch.distributed as dist
 
 
+_OWN_PG = False          # the default process group was created by init_from_env() (so shutdown() may destroy it)
+
+
 def init_from_env(backend: Optional[str] = None) -> Tuple[int, int, int]:
     """(rank, world, local_rank) from the torchrun environment; initialises the default process group if world > 1."""
+    global _OWN_PG
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
@@ -23,7 +27,31 @@ def init_from_env(backend: Optional[str] = None) -> Tuple[int, int, int]:
         if backend is None:     # WFD_DIST_BACKEND=gloo: test rigs where several ranks share one GPU
             backend = os.environ.get("WFD_DIST_BACKEND") or ("nccl" if torch.cuda.is_available() else "gloo")
         dist.init_process_group(backend=backend, rank=rank, world_size=world)
+        _OWN_PG = True
     return rank, world, local
+
+
+def shutdown(destroy: Optional[bool] = None) -> None:
+    """Ordered end of a data-parallel run.  The CALLER first drops every object that holds a HIP graph with captured RCCL
+    nodes (engines, grouped trainers, tail engines: ``del eng, grp, tail``); then this does
+    barrier -> gc.collect() -> torch.cuda.synchronize() -> destroy_process_group().
+    Why the order matters (seen in round 2 as an abort in the test that FOLLOWED a data-parallel one, main thread in plain
+    tensor copies, no capture active): a graph whose nodes were captured from a communicator's collectives outlived that
+    communicator; when the allocator later collected it, RCCL aborted the process.  The barrier keeps the other ranks
+    alive until rank 0 has finished writing its artefacts (they would otherwise tear their communicator down under rank
+    0's last collective).  ``destroy``: None = only a group that init_from_env() created (callers that brought their own
+    group keep it); True / False force it."""
+    global _OWN_PG
+    import gc
+    if not (dist.is_available() and dist.is_initialized()):
+        return
+    dist.barrier()
+    gc.collect()
+    if torch.cuda.is_available():
+        torch.cuda.synchronize()
+    if destroy if destroy is not None else _OWN_PG:
+        dist.destroy_process_group()
+        _OWN_PG = False
 
 
 def graph_capturable(group=None) -> bool:
@@ -134,6 +162,10 @@ class GradSync:
     def finish(self):
         for w in self.pending:
             w.wait()
+        self.pending.clear()
+
+    def reset(self):
+        """Forget the handles of collectives issued under a capture that was abandoned (engine._capture_stages' fallback)."""
         self.pending.clear()
 
 

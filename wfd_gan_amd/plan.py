@@ -67,6 +67,8 @@ class Plan:
         # device tensors that only this plan's launches reference by raw pointer (descriptor tables): they live as long as
         # the plan (and any plan it is concatenated into, and the graphs captured from it, which keep the plan alive)
         self.keep: List[torch.Tensor] = []
+        # thunks that reset host-side collective state (parallel.GradSync.pending ...) when a capture of this plan is abandoned
+        self.abort_hooks: List = []
         self._batch = None                             # wk products being collected for one launch (batch())
         self.lane = 0                                  # stream lane of the launches being added
         self.wsl = 0                                   # lane whose slab workspace they use
@@ -92,6 +94,7 @@ class Plan:
             raise ValueError("plans of different gemm modes cannot be concatenated")
         self.calls += other.calls
         self.keep += other.keep
+        self.abort_hooks += [h for h in other.abort_hooks if h not in self.abort_hooks]
 
     def host(self, thunk, capturable: bool = False):
         """A host-side action between launches (a collective).  ``capturable``: the action only enqueues device work on
