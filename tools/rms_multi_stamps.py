@@ -40,6 +40,26 @@ for rep in range(5):
     rc = fn(arr, len(dims), 5e-5, 0.99, 1e-8, s)
     assert rc == 0, rc
     torch.cuda.synchronize()
+if os.environ.get("WFD_RMS_PERSIST", "1") != "0":
+    # persistent form: 16 slots per workgroup: 0 entry, 1 first tile in LDS, 2 + 2t k-loop of tile t done, 3 + 2t its stores
+    # issued, 15 all stores acknowledged
+    t = st.cpu().numpy().reshape(-1, 16)[:8 * 256].astype(np.float64) * 0.01
+    t = t[t[:, 0] != 0]
+    t0 = t[:, 0].min()
+    q = lambda x: "n %4d  min %.2f  p10 %.2f  p50 %.2f  p90 %.2f  max %.2f" % (len(x), x.min(), np.percentile(x, 10), np.percentile(x, 50), np.percentile(x, 90), x.max())
+    print(f"{which}: K={K}, {len(t)} persistent workgroups")
+    print("entry after first entry ", q(t[:, 0] - t0))
+    print("prologue                ", q(t[:, 1] - t[:, 0]))
+    prev = t[:, 1]
+    for tn in range(6):
+        has = t[:, 2 + 2 * tn] != 0
+        if not has.any():
+            break
+        print(f"tile {tn} k-loop           ", q((t[:, 2 + 2 * tn] - (prev if tn == 0 else t[:, 1 + 2 * tn]))[has]))
+        print(f"tile {tn} rmsprop + stores ", q((t[:, 3 + 2 * tn] - t[:, 2 + 2 * tn])[has]))
+    print("store drain at the end  ", q(t[:, 15] - np.max(t[:, 2:15], axis=1)))
+    print("exit after first entry  ", q(t[:, 15] - t0))
+    sys.exit(0)
 t = st.cpu().numpy()
 t = t[t[:, 0] != 0].astype(np.float64) * 0.01          # us
 t0 = t[:, 0].min()

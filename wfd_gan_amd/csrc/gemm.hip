@@ -424,6 +424,242 @@ __global__ __launch_bounds__(NTHREADS) void gemm_f32_rms_multi_kernel(MultiArgs 
     gemm_f32_body<false, false, 4, 4, false, false, 2>(a.g[k], lds, id % a.gx[k], id / a.gx[k], 0);
 }
 
+// ---- the same launch as PERSISTENT workgroups (round 3; what the step runs) ---------------------------------------------
+// gemm_f32_rms_multi_kernel above deals one 64 x 64 tile to every workgroup: at the critic's shapes that is 1408 workgroups
+// against 768 resident slots, i.e. a full round of workgroups that are all in the same phase at the same time (all loading
+// their first operand tile, then all in their k-loop, then all storing: the stamps of profiles/r02_rms_multi_stamps.txt)
+// followed by a 37 %-full second round that pays the first-tile latency again, and every XCD's L2 fetches every operand
+// panel.  Here `8 * nslots` workgroups (three per CU) stay resident and each walks a LIST of tiles as ONE flattened
+// sequence of k-steps:
+//   * the first operand tile of tile t+1 is requested during the LAST k-step of tile t and is already in LDS when tile
+//     t's store begins, so a tile boundary costs no load latency, and tile t's parameter / square-average stores are in
+//     flight while tile t+1's MFMAs run (the stores of a tile never sit at the end of the launch, except the last one's);
+//   * XCD-aware tile lists: workgroups b and b + 8 share an XCD (round-robin dispatch; used for speed only, any placement
+//     gives the same result), and group x = b % 8 owns a contiguous rows x columns SLAB of every problem's tile grid, so an
+//     XCD's L2 fetches only its slab's operand panels (host picks the 8x1 / 4x2 / 2x4 / 1x8 split per problem that balances
+//     the tile counts and then minimises panel fetches).
+// Every tile is computed exactly as gemm_f32_body<false, false, 4, 4, false, false, 2> computes it (same k order, same
+// MFMA sequence, same rmsprop_update), so the launch is bit-identical to the one-tile-per-workgroup form; which workgroup
+// computes a tile cannot matter.  Exit: a workgroup leaves when its list index passes the group's tile count (static lists,
+// no queue, no flag, no wait on another workgroup).
+struct PersistArgs {
+    MultiArgs m;
+    int small_blocks, nslots;
+    int gy[MULTI_MAX], lpr[MULTI_MAX];       // tile rows of problem k; its grid is split 2^lpr x 2^(3 - lpr) over the XCD groups
+    unsigned long long* stamps;              // diagnostic build only (WFD_STAMPS): 16 s_memrealtime slots per workgroup
+};
+#ifdef WFD_STAMPS
+#define WFD_PSTAMP(slot) if (a.stamps && threadIdx.x == 0 && (slot) < 16) a.stamps[(long)blockIdx.x * 16 + (slot)] = __builtin_amdgcn_s_memrealtime();
+#else
+#define WFD_PSTAMP(slot)
+#endif
+
+// slab of XCD group x in a gy x gx tile grid split pr x pc (pr = 2^lpr, pc = 8 / pr): rows [rlo, rhi) x columns [clo, chi)
+__host__ __device__ __forceinline__ void persist_slab(int gy, int gx, int lpr, int x, int& rlo, int& rhi, int& clo, int& chi) {
+    const int lpc = 3 - lpr, xr = x >> lpc, xc = x & ((1 << lpc) - 1);
+    rlo = (gy * xr) >> lpr; rhi = (gy * (xr + 1)) >> lpr;
+    clo = (gx * xc) >> lpc; chi = (gx * (xc + 1)) >> lpc;
+}
+
+// RB = row blocks of 32 per wave: 1 -> 64 x 64 tiles, three workgroups per CU (any problem); 2 -> 128 x 64 tiles (each wave
+// 64 x 32: two accumulators sharing every B fragment), two workgroups per CU -- half the operand bytes staged per MFMA, and
+// a k-step's 32 MFMAs per wave cover the latency of the next operand tile's loads even while the operands are still cold in
+// the XCD's L2 (all workgroups of a group walk k in step, so every k-step's first touch is a miss for all of them).
+template <int RB, int WPE>
+__global__ __launch_bounds__(NTHREADS, WPE) void gemm_f32_rms_persist_kernel(PersistArgs a) {
+    constexpr int BMT = 64 * RB, NSUB = RB + 1, BUF_F = NSUB * TILE_F;       // A sub-tiles of 64 rows, then the B tile
+    __shared__ __attribute__((aligned(16))) float lds[2 * BUF_F];
+    const int b = blockIdx.x;
+    if (b < a.small_blocks) {                                           // uniform over the workgroup
+        int id = b;
+        if (id < a.m.cs_blocks) { colsum_multi_body256<true>(a.m.cs_desc, a.m.cs_nseg, a.m.cs, id, lds); return; }
+        id -= a.m.cs_blocks;
+        if (id < a.m.rr_blocks) {
+            rmsprop_ranges_body(a.m.cs.pbase, a.m.cs.gbase, a.m.cs.sqbase, a.m.rr, a.m.cs.lr, a.m.cs.alpha, a.m.cs.eps,
+                                (long)id * NTHREADS + threadIdx.x);
+            return;
+        }
+        id -= a.m.rr_blocks;
+        bn_running_layer_body(id / a.m.bn.bn_blocks ? a.m.bn.b : a.m.bn.a, (id % a.m.bn.bn_blocks) * NTHREADS + threadIdx.x,
+                              a.m.bn.count, a.m.bn.momentum, a.m.bn.groups, a.m.bn.nupd_last);
+        return;
+    }
+    const int x = b & 7;                                                // workgroups b and b + 8 share an XCD
+    const int slot = (b - (a.small_blocks + ((x - a.small_blocks) & 7))) >> 3;
+    // tile qq of this group -> (problem, tile row, tile column): the group's slabs in problem order, row-major inside a
+    // slab; false when the list is exhausted.  All scalar (uniform over the workgroup); the argument block is indexed
+    // statically so that it stays in the kernarg segment.
+    const int np = a.m.n;
+    const int gy0 = a.gy[0], gy1 = a.gy[1], gy2 = a.gy[2], gy3 = a.gy[3];
+    const int gx0 = a.m.gx[0], gx1 = a.m.gx[1], gx2 = a.m.gx[2], gx3 = a.m.gx[3];
+    const int lp0 = a.lpr[0], lp1 = a.lpr[1], lp2 = a.lpr[2], lp3 = a.lpr[3];
+    auto decode = [&](int qq, int& k, int& by, int& bx) -> bool {
+        bool found = false;
+        k = by = bx = 0;
+        auto try_k = [&](int t, int gy, int gx, int lpr) {
+            if (t < np && !found) {
+                int rlo, rhi, clo, chi;
+                persist_slab(gy, gx, lpr, x, rlo, rhi, clo, chi);
+                const int w = chi - clo, c = (rhi - rlo) * w;
+                if (qq < c) { found = true; k = t; by = rlo + qq / w; bx = clo + qq % w; }
+                else qq -= c;
+            }
+        };
+        try_k(0, gy0, gx0, lp0); try_k(1, gy1, gx1, lp1); try_k(2, gy2, gx2, lp2); try_k(3, gy3, gx3, lp3);
+        return found;
+    };
+    int q = slot, k, by, bx;
+    if (!decode(q, k, by, bx)) return;
+    WFD_PSTAMP(0)
+    int tno = 0;
+    (void)tno;
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1, i = lane & 31, h = lane >> 5;
+    // the fields of the problem a tile belongs to: operands (until the tile's last loads are out) / parameters (until its
+    // store).  Read through the kernarg segment pointer with a uniform dynamic index (scalar loads at a computed offset):
+    // indexing the by-value argument itself with a runtime index makes the compiler copy all of it to private memory.
+    struct Opnd { const float* A; const float* B; int M, N, K, lda, ldb; };
+    struct Parm { float* P; float* sq; int M, N, ldp; };
+    const PersistArgs* ap = (const PersistArgs*)__builtin_amdgcn_kernarg_segment_ptr();
+    auto opnd = [&](int kk) {
+        const GemmArgs& s = ap->m.g[kk];
+        return Opnd{s.A, s.B, s.M, s.N, s.K, s.lda, s.ldb};
+    };
+    auto parm = [&](int kk) {
+        const GemmArgs& s = ap->m.g[kk];
+        return Parm{s.P, s.sq, s.M, s.N, s.ldp};
+    };
+    Opnd g = opnd(k);
+    Parm pm = parm(k);
+    int m0 = by * BMT, n0 = bx * BN, nk = (g.K + BK - 1) / BK;
+    int offa[RB][2], offb[2], lp[2];
+    float ra[RB][8], rb[8], pp[RB][16], sv[RB][16];
+    auto offsets = [&](const Opnd& gg, int mm0, int nn0) {
+#pragma unroll
+        for (int j = 0; j < RB; ++j) tile_offsets<false, false>(offa[j], lp, gg.lda, mm0 + 64 * j, gg.M, 0, tid, 0, 0, 0);
+        tile_offsets<false, false>(offb, lp, gg.ldb, nn0, gg.N, 0, tid, 0, 0, 0);
+    };
+    auto load_both = [&](const Opnd& gg, int mm0, int nn0, int kt) {
+        const int k0 = kt * BK;
+        if (k0 + BK <= gg.K) {                                          // wave-uniform: interior k-tile
+#pragma unroll
+            for (int j = 0; j < RB; ++j) load_tile_fast<false, false>(ra[j], gg.A, offa[j], lp, kt * BK * gg.lda, k0, tid, 0, 0);
+            load_tile_fast<false, false>(rb, gg.B, offb, lp, kt * BK * gg.ldb, k0, tid, 0, 0);
+        } else {
+#pragma unroll
+            for (int j = 0; j < RB; ++j)
+                load_tile<false, 4, false>(ra[j], gg.A, gg.lda, mm0 + 64 * j, gg.M, k0, gg.K, tid, 0, 0, 0);
+            load_tile<false, 4, false>(rb, gg.B, gg.ldb, nn0, gg.N, k0, gg.K, tid, 0, 0, 0);
+        }
+    };
+    int cur = 0;
+    auto park = [&](int buf) {          // the operand tile in registers -> LDS buffer `buf`
+#pragma unroll
+        for (int j = 0; j < RB; ++j) store_tile<false, 4>(ra[j], lds + buf * BUF_F + j * TILE_F, tid);
+        store_tile<false, 4>(rb, lds + buf * BUF_F + RB * TILE_F, tid);
+    };
+    f32x16 acc[RB];
+#pragma unroll
+    for (int j = 0; j < RB; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
+    offsets(g, m0, n0);
+    load_both(g, m0, n0, 0);
+    park(0);
+    __syncthreads();
+    WFD_PSTAMP(1)
+    // wave (wm, wn): RB = 1: rows wm * 32 of the one A sub-tile; RB = 2: both 32-row blocks of A sub-tile wm; columns wn * 32
+    auto mfma_block = [&]() {
+        const float* a_s = lds + cur * BUF_F + (RB == 2 ? wm * TILE_F : 0);
+        const float* b_s = lds + cur * BUF_F + RB * TILE_F;
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) {
+            const f32x4 bv = read_frag<false>(b_s, wn * 32, kk, i, h);
+#pragma unroll
+            for (int j = 0; j < RB; ++j) {
+                const f32x4 av = read_frag<false>(a_s, RB == 2 ? j * 32 : wm * 32, kk, i, h);
+#pragma unroll
+                for (int s = 0; s < 4; ++s) acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[s], bv[s], acc[j], 0, 0, 0);
+            }
+        }
+    };
+    // first row of accumulator block j of this wave, inside the tile
+    auto row0 = [&](int j) { return RB == 2 ? wm * 64 + j * 32 : wm * 32; };
+    auto prefetch_params = [&]() {
+        // parameter / square-average tile: requested behind the LAST operand tile's loads (loads retire in order)
+        const int pcol = min(n0 + wn * 32 + i, pm.N - 1);
+#pragma unroll
+        for (int j = 0; j < RB; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int prow = min(m0 + row0(j) + (r & 3) + 8 * (r >> 2) + 4 * h, pm.M - 1);
+                pp[j][r] = pm.P[(long)prow * pm.ldp + pcol];
+                sv[j][r] = pm.sq[(long)prow * pm.ldp + pcol];
+            }
+    };
+    for (;;) {
+        // k-steps 0 .. nk-3: next operand tile of THIS output tile
+        for (int kt = 0; kt + 2 < nk; ++kt) {
+            load_both(g, m0, n0, kt + 1);
+            mfma_block();
+            park(cur ^ 1);
+            __syncthreads();
+            cur ^= 1;
+        }
+        if (nk >= 2) {                  // k-step nk-2: the last operand tile, and behind it the parameter tile
+            load_both(g, m0, n0, nk - 1);
+            prefetch_params();
+            mfma_block();
+            park(cur ^ 1);
+            __syncthreads();
+            cur ^= 1;
+        } else {
+            prefetch_params();
+        }
+        // k-step nk-1: the NEXT output tile's first operand tile is requested here and parked in LDS behind the MFMAs
+        int kn, byn, bxn;
+        const bool has_next = decode(q + a.nslots, kn, byn, bxn);       // uniform over the workgroup
+        const int m0n = byn * BMT, n0n = bxn * BN;
+        if (has_next) {
+            g = opnd(kn);
+            offsets(g, m0n, n0n);
+            load_both(g, m0n, n0n, 0);
+        }
+        mfma_block();
+        if (has_next) park(cur ^ 1);
+        __syncthreads();
+        cur ^= 1;
+        WFD_PSTAMP(2 + 2 * tno)
+        // the tile's store: RMSprop on the prefetched parameter tile (C/D map of the 32 x 32 accumulator as in gemm_f32_body)
+        const int col = n0 + wn * 32 + i;
+        if (col < pm.N) {
+#pragma unroll
+            for (int j = 0; j < RB; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int row = m0 + row0(j) + (r & 3) + 8 * (r >> 2) + 4 * h;
+                    if (row < pm.M) {
+                        rmsprop_update(pp[j][r], sv[j][r], acc[j][r], a.m.g[0].lr, a.m.g[0].alpha, a.m.g[0].eps);
+                        pm.sq[(long)row * pm.ldp + col] = sv[j][r];
+                        pm.P[(long)row * pm.ldp + col] = pp[j][r];
+                    }
+                }
+        }
+        WFD_PSTAMP(3 + 2 * tno)
+#ifdef WFD_STAMPS
+        ++tno;
+        if (!has_next) { __builtin_amdgcn_s_waitcnt(0); WFD_PSTAMP(15) }
+#endif
+        if (!has_next) break;
+#pragma unroll
+        for (int j = 0; j < RB; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
+        q += a.nslots; pm = parm(kn); m0 = m0n; n0 = n0n; nk = (g.K + BK - 1) / BK;
+    }
+}
+
 template <bool AKC, bool BKC, bool IM2COL, bool NARROW, int EPI>
 int launch_gemm2(const GemmArgs& g, int splits, bool va4, bool vb4, hipStream_t st) {
     dim3 grid(NARROW ? cdiv(g.N, 32) : cdiv(g.N, BN), cdiv(g.M, BM), splits), block(NTHREADS);
@@ -1098,6 +1334,53 @@ static int rms_multi_launch(const long long* desc, int n, float lr, float alpha,
         a.g[k].D = reinterpret_cast<const float*>(g_multi_stamps + (long)k * g_multi_nslots * 4); a.g[k].ldd = g_multi_nslots;
     }
 #endif
+    // (the switches: same-session A/B.  WFD_RMS_PERSIST=0: one tile per workgroup; WFD_RMS_RB: 1 = 64 x 64 tiles at three
+    // workgroups per CU, 2 = 128 x 64 tiles at two per CU; WFD_RMS_SLOTS: persistent workgroups per XCD group)
+    static const int persist = getenv("WFD_RMS_PERSIST") ? atoi(getenv("WFD_RMS_PERSIST")) : 1;
+    static const int rb_env = getenv("WFD_RMS_RB") ? atoi(getenv("WFD_RMS_RB")) : 1;
+    static const int slots_env = getenv("WFD_RMS_SLOTS") ? atoi(getenv("WFD_RMS_SLOTS")) : 0;
+    if (persist && total >= 8) {
+        PersistArgs pa{};
+        pa.m = a;
+        pa.small_blocks = small_blocks;
+#ifdef WFD_STAMPS
+        pa.stamps = g_multi_stamps;
+#endif
+        const int rb = rb_env == 2 ? 2 : 1;
+        long worst = 0;
+        for (int k = 0; k < n; ++k) {
+            // split of problem k's gy x gx tile grid over the 8 XCD groups as pr x pc slabs: least tiles on the fullest
+            // group first, then fewest operand panels fetched per group (rows + columns of a slab)
+            const int gx = a.gx[k], gy = cdiv(a.g[k].M, 64 * rb);
+            int best_lpr = 3; long best_cost = -1;
+            for (int lpr = 0; lpr <= 3; ++lpr) {
+                const int pr = 1 << lpr, pc = 8 >> lpr;
+                const long mx = (long)cdiv(gy, pr) * cdiv(gx, pc);
+                const long cost = mx * 100000 + cdiv(gy, pr) * rb + cdiv(gx, pc);
+                if (best_cost < 0 || cost < best_cost) { best_cost = cost; best_lpr = lpr; }
+            }
+            pa.gy[k] = gy; pa.lpr[k] = best_lpr;
+        }
+        for (int k = n; k < MULTI_MAX; ++k) { pa.gy[k] = 1; pa.lpr[k] = 0; pa.m.gx[k] = 1; }
+        for (int x = 0; x < 8; ++x) {
+            long c = 0;
+            for (int k = 0; k < n; ++k) {
+                int rlo, rhi, clo, chi;
+                persist_slab(pa.gy[k], pa.m.gx[k], pa.lpr[k], x, rlo, rhi, clo, chi);
+                c += (long)(rhi - rlo) * (chi - clo);
+            }
+            if (c > worst) worst = c;
+        }
+        int nslots = slots_env >= 1 ? slots_env : (rb == 2 ? 64 : 96);
+        if (nslots > worst) nslots = (int)worst;            // never more workgroups than the fullest group has tiles
+        pa.nslots = nslots;
+        const dim3 grid((unsigned)(small_blocks + 8 * nslots));
+        hipStream_t st = (hipStream_t)stream;
+        if (rb == 2) hipLaunchKernelGGL((gemm_f32_rms_persist_kernel<2, 2>), grid, dim3(NTHREADS), 0, st, pa);
+        else hipLaunchKernelGGL((gemm_f32_rms_persist_kernel<1, 3>), grid, dim3(NTHREADS), 0, st, pa);
+        WFD_CHECK_LAUNCH();
+        return WFD_OK;
+    }
     hipLaunchKernelGGL(gemm_f32_rms_multi_kernel, dim3((unsigned)(total + small_blocks)), dim3(NTHREADS), 0, (hipStream_t)stream, a);
     WFD_CHECK_LAUNCH();
     return WFD_OK;
