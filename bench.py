@@ -200,6 +200,96 @@ def cpu_baseline(args, seconds=20.0):
                 sample=f"{n} iterations of the same config-2 step (B={B}, S={S}) on {threads} host threads")
 
 
+def cli_epoch(device, epochs=4, extra=()):
+    """Steady-state epochs of the trainer CLI (wfd_gan_amd.mlp_df_wgan_train.main, the reference's flags) on the config-2
+    dataset: 1562 full batches + a tail of 32 per epoch, the DF-accuracy pass over the epoch's ~33 k generated traces and all
+    per-epoch host work included; log line to log line from epoch 2 on (start-up, graph capture and the epoch-1 checkpoint
+    drop out)."""
+    import logging
+    import shutil
+    import tempfile
+    from wfd_gan_amd import mlp_df_wgan_train
+    from wfd_gan_amd.model import DF
+    X, y = synth_dataset_device(100, 1000, 1400, 50, 75, 179, 0, device)
+    # burst counts capped at L - 1: with a count of L in the data the length head can reach index S, where the reference
+    # raises IndexError (src/model.py:44) and so does this trainer at the epoch's end
+    full = X[:, 0] >= 1400
+    X[full, 0] = 1399
+    X[full, 1400] = 0
+    tmp = tempfile.mkdtemp(prefix="wfd_epoch_")
+    try:
+        ddir = os.path.join(tmp, "set", "feature")
+        os.makedirs(ddir)
+        npz = os.path.join(ddir, "raw_feature_synth.npz")
+        np.savez(npz, features=X.cpu().numpy().astype(np.float64), labels=y.cpu().numpy().astype(np.int64))
+        del X, y
+        torch.manual_seed(0)
+        ck = os.path.join(tmp, "df.ckpt")
+        torch.save(DF(1400, 100).state_dict(), ck)
+        stamps = []
+
+        class Stamp(logging.Handler):
+            def emit(self, record):
+                if "[Epoch" in record.getMessage():
+                    torch.cuda.synchronize()
+                    stamps.append(time.perf_counter())
+
+        orig = mlp_df_wgan_train.utils.init_logger
+
+        def init_logger(*a, **k):
+            lg = orig(*a, **k)
+            lg.handlers = [h for h in lg.handlers if isinstance(h, logging.FileHandler)]     # keep stdout to the JSON line
+            lg.addHandler(Stamp())
+            return lg
+        mlp_df_wgan_train.utils.init_logger = init_logger
+        try:
+            mlp_df_wgan_train.main(["-d", npz, "--f_model", ck, "--n_epochs", str(epochs), "--freq", "1000", "--seed", "1"]
+                                   + list(extra))
+        finally:
+            mlp_df_wgan_train.utils.init_logger = orig
+        # the epoch-1 checkpoint (savez_compressed of 33 k rows: seconds) is written AFTER epoch 1's log line: time from
+        # epoch 2's line on
+        ep = (stamps[-1] - stamps[1]) / (len(stamps) - 2)
+        return dict(seconds_per_epoch=ep, iterations_per_s=1563 / ep, epochs_timed=len(stamps) - 2,
+                    note="python -m wfd_gan_amd.mlp_df_wgan_train on the config-2 npz: 1563 iterations per epoch (1562 full "
+                         "batches + the ragged tail), DF-accuracy pass over the epoch's generated traces, loss read-out and "
+                         "logging included; epochs 3.. (epoch 1 carries start-up and graph capture, its checkpoint is written "
+                         "during epoch 2's interval)")
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
+
+
+def launch_times(eng, plan, rep=8, rounds=2):
+    """Isolated device time of EVERY launch of a plan (not only the contractions): each launch replayed `rep` times in a
+    graph of its own between HIP events, as gemm_roofline does.  Launches that update state (optimizer, counters, running
+    statistics) are repeated too, so the caller snapshots and restores the training state around this."""
+    from wfd_gan_amd.parallel import graph_capture_kwargs
+    from wfd_gan_amd.plan import FORK, HOST, JOIN
+    eng.L.set_gemm_mode(eng.gemm_mode)
+    tot, n = 0.0, 0
+    for fn, a, _lane in plan.calls:
+        if fn is FORK or fn is JOIN or fn is HOST:
+            continue
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g, **graph_capture_kwargs()):
+            st = torch.cuda.current_stream().cuda_stream
+            for _ in range(rep):
+                fn(*a, st)
+        g.replay()
+        t = 0.0
+        for _ in range(rounds):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            g.replay()
+            e1.record()
+            e1.synchronize()
+            t += e0.elapsed_time(e1) / rep
+        tot += t / rounds
+        n += 1
+    eng.L.set_gemm_mode(0)
+    return n, tot * 1e3          # launches, sum of their isolated times in us
+
+
 def self_launch(n: int) -> int:
     """`python bench.py --gpus N` without a torchrun environment: start N fresh rank processes of this same command line
     (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* set as torch.distributed.run would), relay their output and return the first
@@ -275,6 +365,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-sampling", action="store_true")
     ap.add_argument("--no-modes", action="store_true", help="skip the bf16x3 / bf16 operand-mode runs of the same step")
+    ap.add_argument("--no-extras", action="store_true",
+                    help="skip the short WGAN-GP (--penalty gp) block, the trainer-CLI epoch and the per-launch time sum")
     ap.add_argument("--cpu-seconds", type=float, default=20.0)
     args = ap.parse_args()
 
@@ -478,6 +570,47 @@ def main():
             torch.cuda.empty_cache()
         modes["note"] = ("same config-2 step, contractions as bf16 MFMA over the fp32 data: bf16x3 = split-bf16 (products ~1e-5 "
                          "relative, meets the 1e-3 parity bar: tests/test_gpu_step.py), bf16 = bf16 operands (config 4 numerics)")
+    # driver-visible extras (world 1, headline configuration only): the launch structure of a group, the same step with the
+    # interpolated WGAN-GP penalty north_star names (src/utils.py:64-84; 3 B stacked critic rows), one trainer-CLI epoch
+    extras = {}
+    if world == 1 and grouped and not args.no_extras and not args.no_graph:
+        from wfd_gan_amd.engine import GroupedTrainer
+        snap, gfs = eng._snapshot(), eng.gf_state.clone()
+        nl, us = launch_times(eng, drv.group)
+        torch.cuda.synchronize()
+        eng._restore(snap)
+        eng.gf_state.copy_(gfs)
+        group_us = ms_per_step * 1e3 * eng.n_critic
+        extras["launches_per_group"] = nl
+        extras["kernel_time_fraction"] = {
+            "sum_isolated_launch_us": us, "group_wall_us": group_us, "frac": us / group_us,
+            "note": f"sum over the {nl} launches of one group of {eng.n_critic} iterations (each replayed 8x back to back in a "
+                    "graph of its own, hot operands) / wall time of a group in the timed blocks; the difference is launch "
+                    "boundaries and cold first tiles"}
+        if args.penalty == "div":
+            a2 = argparse.Namespace(**vars(args))
+            a2.penalty = "gp"
+            e2, _ = build_engine(a2, rank, world, device)
+            d2 = GroupedTrainer(e2, graphs=True)
+            n2 = max(args.steps - args.steps % eng.n_critic, eng.n_critic)
+            run_steps(d2, 0, 30)
+            dts2 = []
+            for _ in range(3):
+                torch.cuda.synchronize()
+                t2 = time.perf_counter()
+                run_steps(d2, 30, n2)
+                torch.cuda.synchronize()
+                dts2.append(time.perf_counter() - t2)
+            r2 = gemm_roofline(e2, [(d2.group, 1)])
+            extras["penalty_gp"] = {"iterations_per_s": n2 / float(np.median(dts2)), "core_tflops": r2["tflops"],
+                                    "frac_of_f32_mfma_peak": r2["tflops"] / PEAK_F32_MFMA_TFLOPS,
+                                    "avg_us_per_launch": r2["avg_us"], "launches_timed": r2["launches"],
+                                    "note": "same config-2 step with --penalty gp (interpolates as a third row group of the "
+                                            "critic input: 192 stacked rows; parity: tests/test_gpu_gp_and_cli.py)"}
+            del d2, e2
+            torch.cuda.empty_cache()
+        if args.operands == "f32" and args.batch == 64 and args.seq_len == 1401 and args.classes == 100 and args.inst == 1000:
+            extras["cli_epoch"] = cli_epoch(device)
     if rank == 0:
         out = {
             "metric": "WGAN train iterations/s (100-class, L=1400, fp32; one iteration = loop body on one 64-row batch: "
@@ -510,6 +643,7 @@ def main():
                          "kernel": core, "launches_timed": roof["launches"],
                          "avg_flops_per_launch": roof["avg_flops"], "avg_us_per_launch": roof["avg_us"]},
         }
+        out.update(extras)
         if samp:
             out["sampling"] = samp
         if modes:

@@ -6,60 +6,21 @@ drop out."""
 import json
 import os
 import sys
-import tempfile
 import time
 
 import numpy as np
 import torch
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-sys.argv = ["bench.py"]
+EXTRA = sys.argv[1:]          # extra trainer flags, e.g. --operands bf16x3
 import bench  # noqa: E402
-from wfd_gan_amd import mlp_df_wgan_train  # noqa: E402
-from wfd_gan_amd.model import DF  # noqa: E402
 
 
 def main():
-    dev = torch.device("cuda:0")
-    X, y = bench.synth_dataset_device(100, 1000, 1400, 50, 75, 179, 0, dev)
-    # burst counts capped at L - 1: with a count of L in the data the length head can reach index S, where the
-    # reference raises IndexError (src/model.py:44) and so does this trainer at the epoch's end
-    full = X[:, 0] >= 1400
-    X[full, 0] = 1399
-    X[full, 1400] = 0
-    tmp = tempfile.mkdtemp(prefix="wfd_epoch_")
-    ddir = os.path.join(tmp, "set", "feature")
-    os.makedirs(ddir)
-    npz = os.path.join(ddir, "raw_feature_synth.npz")
-    np.savez(npz, features=X.cpu().numpy().astype(np.float64), labels=y.cpu().numpy().astype(np.int64))
-    torch.manual_seed(0)
-    ck = os.path.join(tmp, "df.ckpt")
-    torch.save(DF(1400, 100).state_dict(), ck)
-    import logging
-    stamps = []
-
-    class Stamp(logging.Handler):
-        def emit(self, record):
-            if "[Epoch" in record.getMessage():
-                torch.cuda.synchronize()
-                stamps.append(time.perf_counter())
-
-    orig = mlp_df_wgan_train.utils.init_logger
-
-    def init_logger(*a, **k):
-        lg = orig(*a, **k)
-        lg.addHandler(Stamp())
-        return lg
-    mlp_df_wgan_train.utils.init_logger = init_logger
-    mlp_df_wgan_train.main(["-d", npz, "--f_model", ck, "--n_epochs", "5", "--freq", "1000", "--seed", "1"] + sys.argv[1:])
-    # epoch 1 is followed by its checkpoint; epochs 3..5 are steady state (log line to log line)
-    ep = (stamps[4] - stamps[1]) / 3
-    print(json.dumps(dict(metric="trainer CLI seconds per epoch (config 2: 1563 iterations + DF accuracy pass over the "
-                                 "epoch's 33k generated traces + per-epoch host work)",
-                          seconds_per_epoch=ep, iterations_per_s=1563 / ep, extra_args=sys.argv[1:])))
+    r = bench.cli_epoch(torch.device("cuda:0"), epochs=5, extra=EXTRA)
+    r["extra_args"] = EXTRA
+    print(json.dumps(r))
 
 
 if __name__ == "__main__":
-    extra = sys.argv[1:]
-    sys.argv = [sys.argv[0]] + extra
     main()
