@@ -568,7 +568,9 @@ def main():
                          "avg_us_per_launch": r2["avg_us"]}
             del d2, e2
             torch.cuda.empty_cache()
-        modes["note"] = ("same config-2 step, contractions as bf16 MFMA over the fp32 data: bf16x3 = split-bf16 (products ~1e-5 "
+        modes["note"] = ("same config-2 step and the SAME launch structure as the headline (weight gradients through the "
+                         "f32-operand launch with RMSprop in its store, merged step ends: like for like since round 3); only the "
+                         "forward / chain contractions run as bf16 MFMA over the fp32 data: bf16x3 = split-bf16 (products ~1e-5 "
                          "relative, meets the 1e-3 parity bar: tests/test_gpu_step.py), bf16 = bf16 operands (config 4 numerics)")
     # driver-visible extras (world 1, headline configuration only): the launch structure of a group, the same step with the
     # interpolated WGAN-GP penalty north_star names (src/utils.py:64-84; 3 B stacked critic rows), one trainer-CLI epoch

@@ -93,12 +93,38 @@ def _engine(st, meta, **kw):         # noqa: E302 (used by the tests above and b
                        st.DF, lr=meta["lr"], alpha=meta["alpha"], n_critic=meta["n_critic"], **kw)
 
 
-def test_fused_optimizer_is_f32_mode_only():
-    """The bf16-pipe operand modes keep the flat optimizer pass (their fused store has no prefetch and measured slower)."""
-    fx, meta = load_iter_fixture("tiny")
-    st = rebuild_state(meta, fx)
-    e = _engine(st, meta, fuse_opt=True, operands="bf16x3")
-    assert not e.fuse_d and not e.fuse_g
+def test_fused_optimizer_in_every_operand_mode():
+    """Round 3: the bf16-pipe operand modes run the f32 mode's launch structure (weight gradients through the f32-operand
+    wfd_gemm_f32_rmsprop_multi launch with RMSprop in its store, merged step ends), so bench.py's operand_modes compare the
+    arithmetic of the forward / chain contractions only.  One iteration in bf16x3 mode, fused vs gradient buffers + flat
+    pass: the weight gradients of the fused form are exact-f32 products, those of the flat form split-bf16 ones (~1e-5
+    relative), so the parameters agree to that -- not to the bit."""
+    fx, meta = load_iter_fixture("cfg1")
+    B = meta["batch"]
+    engs = []
+    for fuse in (True, False):
+        st = rebuild_state(meta, fx)
+        e = _engine(st, meta, fuse_opt=fuse, operands="bf16x3")
+        assert bool(e.fuse_d) == fuse and bool(e.fuse_g) == fuse
+        mr, mf, mg = (unpack_masks(fx, "it0_" + k, B) for k in ("mreal", "mfake", "mg"))
+        e.set_batch(*(torch.from_numpy(a) for a in iter_inputs(fx, meta, 0)))
+        e.set_masks([torch.cat([a, b]) for a, b in zip(mr, mf)], mg)
+        before = (e.Dp.flat.clone(), e.Gp.flat.clone())
+        e.d_step()
+        e.g_step()
+        torch.cuda.synchronize()
+        engs.append((e.Dp.flat - before[0], e.Gp.flat - before[1]))
+    for a, b in zip(*engs):
+        # first RMSprop step: lr g / (0.1 |g| + eps) -- ~10 lr in the direction of g's sign for |g| >> 1e-7, proportional to g
+        # below.  A weight-gradient element is a sum over the batch rows with cancellation, so the split-bf16 products' 1e-5
+        # relative error is a much larger relative error of the small elements: measured 92 % of the updates within 1e-3 of
+        # the step size.  Required: most updates agree closely, nearly all agree in direction, none is off by more than the
+        # two-step distance a sign flip gives.
+        step = 10 * meta["lr"]
+        assert ((a - b).abs() <= 1e-3 * step).float().mean().item() >= 0.85
+        moved = (a.abs() > 0.5 * step) & (b.abs() > 0.5 * step)
+        assert (torch.sign(a[moved]) == torch.sign(b[moved])).float().mean().item() >= 0.995
+        assert float((a - b).abs().max()) <= 2.001 * step
 
 
 @pytest.mark.parametrize("operands", ["f32"])

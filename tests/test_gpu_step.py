@@ -403,8 +403,9 @@ def state_from_engine_(eng, meta, df_state):
     return state_from_engine(eng, meta, df_state)
 
 
-@pytest.mark.parametrize("name", ["cfg1", "cfg2", "cfg4a", "cfg4b"])
-def test_first_iteration_split_bf16_operands(name):
+@pytest.mark.parametrize("name,fuse", [("cfg1", False), ("cfg2", False), ("cfg4a", False), ("cfg4b", False), ("cfg2", True),
+                                       ("cfg1", True)])
+def test_first_iteration_split_bf16_operands(name, fuse):
     """operands="bf16x3" (every contraction as hi*hi + hi*lo + lo*hi on the bf16 matrix pipe, gemm_mx.hip): products
     carry ~1e-5 relative error, so the first iteration (D-step + G-step) must still meet north_star's 1e-3 against the
     reference fixture.  Integer quantities derived from a float threshold (burst-length index, selected-row count) may
@@ -419,7 +420,10 @@ def test_first_iteration_split_bf16_operands(name):
     B = meta["batch"]
     eng = TrainEngine(meta["seq_len"], meta["class_dim"], meta["latent_dim"], B, meta["scaler_min"], meta["scaler_max"],
                       {k: v.detach() for k, v in st.G.items()}, {k: v.detach() for k, v in st.D.items()}, st.DF,
-                      lr=meta["lr"], alpha=meta["alpha"], n_critic=meta["n_critic"], operands="bf16x3")
+                      lr=meta["lr"], alpha=meta["alpha"], n_critic=meta["n_critic"], operands="bf16x3", fuse_opt=fuse)
+    # fuse: the form bench.py's operand_modes and the trainer run on one GPU -- weight gradients through the f32-operand
+    # launch with RMSprop in its store, merged step ends (same launch structure as the f32 mode)
+    assert bool(eng.fuse_d) == fuse and bool(eng.fuse_g) == fuse
     p = "it0_"
     mr, mf, mg = unpack_masks(fx, p + "mreal", B), unpack_masks(fx, p + "mfake", B), unpack_masks(fx, p + "mg", B)
     eng.set_batch(*(torch.from_numpy(a) for a in iter_inputs(fx, meta, 0)))

@@ -1304,7 +1304,9 @@ int wfd_gemm_f32_rmsprop_multi_end(const long long* desc, int n, float lr, float
 static int rms_multi_launch(const long long* desc, int n, float lr, float alpha, float eps, const long long* cs_desc,
                             int cs_nseg, int cs_blocks, const ColsumOpt& cs, void* stream, const RmsRanges* rr, int rr_blocks,
                             const BnRun* bn) {
-    if (!desc || n < 1 || n > MULTI_MAX || g_gemm_mode != 0) return WFD_ERR_ARG;
+    // (runs the f32-operand kernel whatever wfd_set_gemm_mode says: weight gradients contract over the batch rows only
+    // (K = 64 .. 512), where the bf16 pipe buys nothing, so every operand mode shares this launch)
+    if (!desc || n < 1 || n > MULTI_MAX) return WFD_ERR_ARG;
     MultiArgs a{};
     a.cs_desc = cs_desc; a.cs_nseg = cs_nseg; a.cs_blocks = cs_blocks; a.cs = cs;
     if (rr) { a.rr = *rr; a.rr_blocks = rr_blocks; }

@@ -359,9 +359,11 @@ class TrainEngine:
         # the G-step's independent products of equal depth (critic layer k | observer FC layer k, and their two backward
         # chains) share launches; WFD_G_MERGE=0: one launch each (same-session A/B)
         self.g_merge = self.g_tail_fused and not overlap and self.wk and os.environ.get("WFD_G_MERGE", "1") != "0"
-        # (f32 operand mode only: the bf16-pipe core applies the update with the parameter loads inside its store, which costs
-        # more than the flat pass saves -- measured 2743 vs 3076 it/s in bf16x3 mode)
-        fuse = bool(self.fuse_opt) and not self.dp and not overlap and self.gemm_mode == 0
+        # (every operand mode: the weight gradients -- contractions over the 64 .. 256 batch rows, where the bf16 pipe buys
+        # nothing -- always go through the f32-operand launch wfd_gemm_f32_rmsprop_multi, so the bf16 / bf16x3 modes differ from
+        # the f32 mode in the arithmetic of the forward / chain products only and share its launch structure.  Round 2's bf16
+        # modes kept gradient buffers and the flat pass because the bf16-pipe core's own RMSprop store lost: 2743 vs 3076 it/s)
+        fuse = bool(self.fuse_opt) and not self.dp and not overlap
         # the weight gradients contract over 2 M (critic) / B (generator) rows: unsplit below 1024 (Plan.gemm)
         self.fuse_d = fuse and self.fuse_opt != "g" and 2 * M < 1024
         self.fuse_g = fuse and self.fuse_opt != "d" and B < 1024

@@ -293,12 +293,13 @@ class Plan:
     def gemm_rms_multi(self, problems, lr: float, alpha: float = 0.99, eps: float = 1e-8, colsum=None) -> bool:
         """Several independent weight gradients consumed in their stores as ONE launch (wfd_gemm_f32_rmsprop_multi);
         problems: [(A, lda, B, ldb, M, N, K, P, ldp, SQ)] of TN products, at most 4 per launch.  Falls back to one launch
-        each where the fast form does not apply (bf16-pipe modes, narrow or unaligned matrices).
+        each where the fast form does not apply (narrow or unaligned matrices).
         colsum = (desc_ptr, nseg, blocks, gbase, pbase, sqbase, numel, state, inc0, inc1): the launch also carries that
         wfd_colsum_multi_rmsprop (wfd_gemm_f32_rmsprop_multi_colsum); returns True when it did (else the caller launches it)."""
         import ctypes
-        ok = self.gemm_mode == 0 and all(N > 32 and ptr(A) % 16 == 0 and ptr(B) % 16 == 0 and lda % 4 == 0 and ldb % 4 == 0
-                                         for A, lda, B, ldb, M, N, K, P, ldp, SQ in problems)
+        # (every operand mode: the multi launch is the f32-operand kernel -- contractions over the batch rows only)
+        ok = all(N > 32 and ptr(A) % 16 == 0 and ptr(B) % 16 == 0 and lda % 4 == 0 and ldb % 4 == 0
+                 for A, lda, B, ldb, M, N, K, P, ldp, SQ in problems)
         if not ok or len(problems) < 2 or os.environ.get("WFD_RMS_MULTI", "1") == "0":      # (the switch: same-session A/B)
             for A, lda, B, ldb, M, N, K, P, ldp, SQ in problems:
                 self.gemm_rms(TN, A, lda, B, ldb, M, N, K, P, ldp, SQ, lr, alpha, eps)
