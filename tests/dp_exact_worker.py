@@ -114,9 +114,9 @@ def weak_worker(rank, world, port, name, q):
 
 def _run_weak(rank, world, name):
     """Weak (DDP-semantics) mode: every rank steps on its OWN batch (rank r feeds the fixture's iteration-r inputs); the
-    bucketed all-reduce must leave the SUM of the ranks' local gradients in every element of both flat gradient buffers
-    (an element outside every bucket would keep its local value and differ between the ranks), and the replicas must stay
-    bit-identical."""
+    bucketed exchange must apply the SUM of the ranks' local gradients to every element of both parameter buffers (an element
+    outside every bucket / shard would keep its local update and differ between the ranks), and the replicas must stay
+    bit-identical.  Runs the sharded optimizer (default) -- WFD_DP_SHARD=0 in the environment checks round 2's all-reduce form."""
     import torch.distributed as dist
     from tests.util import load_iter_fixture, rebuild_state, unpack_masks
     from wfd_gan_amd import parallel
@@ -151,21 +151,56 @@ def _run_weak(rank, world, name):
     for e in (eng, loc):
         e.set_batch(torch.from_numpy(fx[p + "traces"]), torch.from_numpy(fx[p + "labels"]), torch.from_numpy(fx[p + "z"]))
         e.set_masks([torch.cat([x, y]) for x, y in zip(mr, mf)], mg)
+    before = eng.Dp.flat.clone()
     loc.d_step()
     eng.d_step()
     torch.cuda.synchronize()
-    want = torch.stack(gathered(loc.Dp.grad)).double().sum(0)
+    # the local engine's flat layout differs (bucket starts are padded to 4 * world elements in the data-parallel one): map
+    # the summed local gradients into the data-parallel engine's layout tensor by tensor
+    want = torch.zeros(eng.Dp.numel, dtype=torch.float64)
+    for nme, shape in eng.Dp.specs:
+        eng.Dp._view(want, nme, shape).copy_(torch.stack(gathered(loc.Dp.g[nme].contiguous())).double().sum(0))
     got = gathered(eng.Dp.grad)
-    if not all(torch.equal(got[0], t) for t in got[1:]):
-        bad.append(f"rank {rank}: critic gradient buffers differ between ranks after the all-reduce")
-    err = float((got[0].double() - want).abs().max()) / float(want.abs().max())
-    if err > 1e-6:
-        bad.append(f"rank {rank}: summed critic gradient off by {err:.2e}")
+    if eng.shard:
+        # sharded optimizer: after the reduce-scatter every rank holds the SUM on its own shard of each bucket; the shards
+        # of all ranks together tile the buffer exactly, and the parameters every rank ends up with are the RMSprop step of
+        # that sum (owner's shard, gathered)
+        covered = torch.zeros(eng.Dp.numel, dtype=torch.int32)
+        summed = torch.zeros(eng.Dp.numel, dtype=torch.float64)
+        for lo, hi in eng.grad_buckets("D"):
+            sh = (hi - lo) // world
+            if (hi - lo) % world:
+                bad.append(f"bucket [{lo}, {hi}) does not split over {world} ranks")
+            for r in range(world):
+                a = lo + r * sh
+                covered[a:a + sh] += 1
+                summed[a:a + sh] = got[r][a:a + sh].double()
+        if not bool((covered == 1).all()):
+            bad.append("the ranks' shards do not tile the critic's gradient buffer exactly")
+        err = float((summed - want).abs().max()) / float(want.abs().max())
+        if err > 1e-6:
+            bad.append(f"rank {rank}: reduce-scattered critic gradient off by {err:.2e}")
+        g = want.float() / world
+        sq = 0.01 * g * g
+        step = -meta["lr"] * g / (sq.sqrt() + 1e-8)
+        moved = (eng.Dp.flat.cpu() - before.cpu()).double()
+        big = g.abs() > 1e-6 * float(g.abs().max())
+        perr = float((moved - step.double())[big].abs().max())
+        if perr > 1e-3 * 10 * meta["lr"]:
+            bad.append(f"rank {rank}: critic parameters after the sharded step off by {perr:.2e}")
+    else:
+        if not all(torch.equal(got[0], t) for t in got[1:]):
+            bad.append(f"rank {rank}: critic gradient buffers differ between ranks after the all-reduce")
+        err = float((got[0].double() - want).abs().max()) / float(want.abs().max())
+        if err > 1e-6:
+            bad.append(f"rank {rank}: summed critic gradient off by {err:.2e}")
     eng.g_step()
     eng.d_step()
     torch.cuda.synchronize()
-    for nme, t in (("G grad", eng.Gp.grad), ("D grad", eng.Dp.grad), ("G params", eng.Gp.flat), ("D params", eng.Dp.flat),
-                   ("G sq", eng.Gp.sq), ("D sq", eng.Dp.sq)):
+    # (sharded optimizer: gradients and square averages are only kept on the owner's shard; the PARAMETERS must be identical)
+    for nme, t in ((("G params", eng.Gp.flat), ("D params", eng.Dp.flat)) if eng.shard else
+                   (("G grad", eng.Gp.grad), ("D grad", eng.Dp.grad), ("G params", eng.Gp.flat), ("D params", eng.Dp.flat),
+                    ("G sq", eng.Gp.sq), ("D sq", eng.Dp.sq))):
         parts = gathered(t)
         if not all(torch.equal(parts[0], x) for x in parts[1:]):
             bad.append(f"rank {rank}: {nme} differs between ranks (max |d| = {float((parts[0] - parts[-1]).abs().max()):.3e})")

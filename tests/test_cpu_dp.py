@@ -89,6 +89,76 @@ def test_gradient_allreduce_world2_gloo():
         assert t == [0.0, 0.0, 0.0]
 
 
+class _HostRmsprop:
+    """Stand-in for the library's wfd_rmsprop on HOST memory (same argument list), so that parallel.ShardedSync's bucket /
+    shard / gather logic can run over gloo without a GPU.  Not a product path: the product passes the HIP library."""
+
+    def rmsprop(self, p, g, sq, n, lr, alpha, eps, gscale, state, inc0, inc1, stream):
+        import ctypes
+        arr = lambda ptr: np.ctypeslib.as_array((ctypes.c_float * n).from_address(ptr))
+        pv, gv, sv = arr(p), arr(g), arr(sq)
+        gs = (gv * np.float32(gscale)).astype(np.float32)
+        sv[:] = sv * np.float32(alpha) + np.float32(1.0 - alpha) * gs * gs
+        pv[:] = pv - np.float32(lr) * gs / (np.sqrt(sv) + np.float32(eps))
+
+
+def _shard_worker(rank, world, port, q):
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), MASTER_ADDR="127.0.0.1",
+                      MASTER_PORT=str(port))
+    torch.set_num_threads(2)
+    from wfd_gan_amd import parallel
+    parallel.init_from_env(backend="gloo")
+    n, lr = 12 * world * 7, 2e-4                    # three buckets, each a multiple of the world size
+    buckets = [(8 * world * 7, n), (3 * world * 7, 8 * world * 7), (0, 3 * world * 7)]      # backward order, as grad_buckets()
+    g0 = torch.Generator().manual_seed(1)
+    flat = torch.randn(n, generator=g0)             # identical replicas
+    sq = torch.rand(n, generator=g0)
+    g = torch.Generator().manual_seed(10 + rank)
+    grad = torch.randn(n, generator=g)              # this rank's local gradient
+    parts = [torch.empty_like(grad) for _ in range(world)]
+    dist.all_gather(parts, grad)
+    total = torch.stack(parts).sum(0)
+    want_p, want_sq = flat.clone(), sq.clone()
+    _HostRmsprop().rmsprop(want_p.data_ptr(), total.data_ptr(), want_sq.data_ptr(), n, lr, 0.99, 1e-8, 1.0 / world, 0, 0, 0, 0)
+    ss = parallel.ShardedSync(_HostRmsprop())
+    for lo, hi in buckets:
+        ss.start(flat, grad, sq, lo, hi, lr, 1.0 / world)
+    ss.finish()
+    ok = torch.allclose(flat, want_p, rtol=0, atol=1e-7)          # every element took the step of the SUMMED gradient
+    reps = [torch.empty_like(flat) for _ in range(world)]
+    dist.all_gather(reps, flat)
+    ok = ok and all(torch.equal(reps[0], t) for t in reps[1:])    # replicas bit-identical
+    # the square average is kept by the owner only: own shards updated, the others untouched
+    for lo, hi in buckets:
+        sh = (hi - lo) // world
+        a = lo + rank * sh
+        ok = ok and torch.allclose(sq[a:a + sh], want_sq[a:a + sh], rtol=0, atol=1e-7)
+    try:
+        ss.start(flat, grad, sq, 0, world + 1, lr, 1.0)
+        ok = False                                                # a bucket that does not split evenly must be refused
+    except ValueError:
+        pass
+    dist.barrier()
+    dist.destroy_process_group()
+    q.put((rank, bool(ok)))
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_sharded_optimizer_exchange_over_gloo(world):
+    """parallel.ShardedSync (reduce-scatter -> RMSprop on the rank's shard -> parameter all-gather, per bucket) over gloo on
+    host tensors: every parameter takes the step of the summed gradient, replicas stay bit-identical."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_shard_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=120) for _ in procs]
+    for p in procs:
+        p.join(timeout=30)
+    assert all(ok for _, ok in res), res
+
+
 def test_bench_plain_multi_gpu_launch_is_refused_without_devices():
     """bench.py --gpus 2 with no torchrun environment starts its own ranks -- or, with fewer HIP devices than ranks (none in
     the build container), exits non-zero with a clear message instead of silently running one (VERDICT r2 #1)."""

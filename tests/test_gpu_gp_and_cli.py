@@ -155,8 +155,9 @@ def test_data_parallel_world1_nccl(captured, monkeypatch, nccl_world1):
 
 
 def _data_parallel_world1_nccl(captured, monkeypatch):
-    """The data-parallel code path (bias gradients ahead of the weight gradients, bucketed asynchronous all-reduce over RCCL,
-    flat optimizer pass) with a 1-rank NCCL group must reproduce the single-rank engine bit for bit -- with the collectives
+    """The data-parallel code path (bias gradients ahead of the weight gradients; per bucket reduce-scatter -> RMSprop on the
+    rank's shard -> parameter all-gather over RCCL on a side stream, parallel.ShardedSync) with a 1-rank NCCL group must
+    reproduce the single-rank engine bit for bit -- with the collectives
     captured INSIDE the step graphs (one graph replay per D-step / G-step / group: the default on the "nccl" backend) and
     with them issued eagerly between separately captured stages (WFD_DP_GRAPH=0)."""
     import torch.distributed as dist
@@ -172,8 +173,9 @@ def _data_parallel_world1_nccl(captured, monkeypatch):
         for e in (e1, e2):
             e.attach_dataset(torch.from_numpy(Xs), torch.from_numpy(y), shuffle_seed=5)
             e.capture_graphs()
-        # eager collectives: stage, start, stage, start, stage, start+finish, stage
-        assert len(e2.graph_d) == (1 if captured else 7) and len(e1.graph_d) == 1
+        # eager collectives: stage, chain 0, stage, chain 1, stage, chain 2 + join (the sharded optimizer runs inside the
+        # chains: no optimizer stage behind them)
+        assert len(e2.graph_d) == (1 if captured else 6) and len(e1.graph_d) == 1
         assert (e2.graph_group is not None) == captured
         for i in range(7):
             e1.iteration(i)
@@ -189,7 +191,7 @@ def _data_parallel_world1_nccl(captured, monkeypatch):
             e.attach_dataset(torch.from_numpy(Xs), torch.from_numpy(y), shuffle_seed=5)
             grp = GroupedTrainer(e, graphs=True)
             if e is e3:
-                assert len(grp.stages) == (1 if captured else 1 + 3 * 6 + 6)
+                assert len(grp.stages) == (1 if captured else 4 * 6)
             for _ in range(3):
                 grp.run_group()
             torch.cuda.synchronize()
@@ -199,10 +201,10 @@ def _data_parallel_world1_nccl(captured, monkeypatch):
 
 
 def test_capture_fallback_drops_stale_collective_handles(monkeypatch, nccl_world1):
-    """A capture WITH collectives that fails half-way (here: forced, in the finish() of the first captured D-step, after the
-    three buckets' start() calls ran under the capture) must fall back to eager collectives between graph stages -- and the
-    Work handles created under the abandoned capture must be gone, or the eager retry's first finish() waits on them
-    (ADVICE r2).  The fallback engine then has to reproduce the single-rank engine bit for bit."""
+    """A capture WITH collectives that fails half-way (here: forced, the second bucket's reduce-scatter of the first captured
+    D-step refuses, after the first bucket's chain went into the capture) must fall back to eager collectives between graph stages -- and the
+    host-side state of the abandoned capture (GradSync: Work handles; ShardedSync: the forked side stream) must be gone, or the
+    eager retry's first finish() waits on it.  The fallback engine then has to reproduce the single-rank engine bit for bit."""
     import gc
     import warnings
     from wfd_gan_amd import parallel
@@ -215,22 +217,24 @@ def test_capture_fallback_drops_stale_collective_handles(monkeypatch, nccl_world
     for e in (e1, e2):
         e.attach_dataset(torch.from_numpy(Xs), torch.from_numpy(y), shuffle_seed=5)
     e1.capture_graphs()
-    real_finish, seen = parallel.GradSync.finish, {"forced": 0, "stale": None}
+    import torch.distributed as dist
+    real_rs, seen = dist.reduce_scatter_tensor, {"calls": 0, "forced": 0}
 
-    def finish(self):
+    def refusing_reduce_scatter(*a, **k):
         if torch.cuda.is_current_stream_capturing() and not seen["forced"]:
-            seen["forced"] = 1
-            seen["stale"] = len(self.pending)
-            raise RuntimeError("forced capture failure (test)")
-        return real_finish(self)
-    monkeypatch.setattr(parallel.GradSync, "finish", finish)
+            seen["calls"] += 1
+            if seen["calls"] == 2:             # the second bucket's: the first bucket's chain is already in the capture
+                seen["forced"] = 1
+                raise RuntimeError("forced capture failure (test): collective refused")
+        return real_rs(*a, **k)
+    monkeypatch.setattr(dist, "reduce_scatter_tensor", refusing_reduce_scatter)
     with warnings.catch_warnings(record=True) as w:
         warnings.simplefilter("always")
         e2.capture_graphs()
-    assert seen["forced"] == 1 and seen["stale"] == 3          # three buckets were in flight when the capture died
+    assert seen["forced"] == 1
     assert any("falling back to eager collectives" in str(x.message) for x in w)
-    assert e2._gsync.pending == []
-    assert len(e2.graph_d) == 7                                # stage, start, stage, start, stage, start+finish, stage
+    assert e2._gsync.forked is False and e2._gsync.pending == []
+    assert len(e2.graph_d) == 6                                # stage, chain, stage, chain, stage, chain + join
     for i in range(7):
         e1.iteration(i)
         e2.iteration(i)

@@ -56,15 +56,21 @@ class FlatParams:
     columns).  The pad columns stay zero: their gradient is never written, and RMSprop maps (p=0, g=0, sq=0) to 0.
     ``p[name]`` / ``g[name]`` are views of the logical shape."""
 
-    def __init__(self, specs, device):
+    def __init__(self, specs, device, bucket_starts: Sequence[str] = (), align: int = 4):
+        """bucket_starts / align (data parallel with the sharded optimizer, parallel.ShardedSync): the named tensors -- the
+        first tensor of each gradient bucket -- start at multiples of ``align`` = 4 * world elements and the buffer's length is
+        one too, so that every bucket splits evenly over the ranks into 16-byte aligned shards.  The pad elements stay 0."""
         self.specs = specs
         self.offsets: Dict[str, int] = {}
         self.ld: Dict[str, int] = {}
         off = 0
         for name, shape in specs:
+            if name in bucket_starts:
+                off = rup(off, align)
             self.offsets[name] = off
             self.ld[name] = rup(shape[-1], 4) if len(shape) == 2 else shape[-1]
             off += rup(math.prod(shape[:-1]) * self.ld[name], 4)
+        off = rup(off, align)
         self.numel = off
         self.flat = torch.zeros(off, dtype=torch.float32, device=device)
         self.grad = torch.zeros(off, dtype=torch.float32, device=device)
@@ -261,6 +267,9 @@ class TrainEngine:
         self.force_sync = bool(force_sync)
         self.dp = self.world > 1 or force_sync      # force_sync: run the staged data-parallel path at world 1 (tests)
         self.gscale = 1.0 if self.exact else 1.0 / self.world     # factor RMSprop applies to the summed gradients
+        # data parallel: reduce-scatter -> RMSprop on this rank's shard -> all-gather of the parameters, per bucket
+        # (parallel.ShardedSync); WFD_DP_SHARD=0: all-reduce of the gradients + the full flat pass on every rank (round 2)
+        self.shard = self.dp and os.environ.get("WFD_DP_SHARD", "1") != "0"
         self._comm = None
         self.nbt = {"model.3": 0, "model.6": 0}
         dev = self.dev
@@ -271,8 +280,9 @@ class TrainEngine:
             # optimizer state, BN buffers and packed observer
             self.Gp, self.Dp, self.Gbuf, self.nbt, self.df = share.Gp, share.Dp, share.Gbuf, share.nbt, share.df
         else:
-            self.Gp = FlatParams(G_PARAM_SPECS(S, C, Z), dev)
-            self.Dp = FlatParams(D_PARAM_SPECS(S, C), dev)
+            al = 4 * max(1, self.world)
+            self.Gp = FlatParams(G_PARAM_SPECS(S, C, Z), dev, ("model.5.weight", "model.8.weight"), al)
+            self.Dp = FlatParams(D_PARAM_SPECS(S, C), dev, ("model.3.weight", "model.6.weight"), al)
             self.Gp.load(G_state)
             self.Dp.load(D_state)
             self.Gbuf = {k: G_state[k].detach().to(**f32).clone() for k in G_BUFFER_KEYS}
@@ -602,7 +612,7 @@ class TrainEngine:
             return p
         if self.overlap:
             p.join()
-        self._grad_sync_hook(p, "D")
+        self._grad_sync_hook(p, "D", st_arg)
         self._optimizer(p, D, False, *st_arg)
         return p
 
@@ -610,6 +620,8 @@ class TrainEngine:
         """optimizer.step() (:230, :275): the flat RMSprop pass, or -- the matrices having been updated in their gradients'
         stores -- the vectors only.  Either also advances the device-resident Philox counter / batch cursor."""
         if not fused:
+            if self.shard:          # done shard by shard inside the buckets' chains (_grad_bucket_hook)
+                return
             p.add(self.L.rmsprop, ptr(fp.flat), ptr(fp.grad), ptr(fp.sq), fp.numel, self.lr, 0.99, 1e-8, self.gscale,
                   state, inc0, inc1)
             return
@@ -668,7 +680,7 @@ class TrainEngine:
             p.add(self.L.colsum_multi_rmsprop, ptr(desc), len(rows), blk, ptr(fp.grad), ptr(fp.flat), ptr(fp.sq), fp.numel,
                   self.lr, 0.99, 1e-8, state, inc0, inc1)
 
-    def _grad_bucket_hook(self, p: Plan, which: str, stage: int):
+    def _grad_bucket_hook(self, p: Plan, which: str, stage: int, st_arg=None):
         """Data parallel: all-reduce the flat gradient buffer in three buckets, each launched (asynchronously, on the
         collective's stream) as soon as its slice is final, so that only the last, small one is exposed:
           critic     0: [W1, b1] (12.3 MB, right after the first weight-gradient GEMM)   1: [W2, b2] (8.4 MB)
@@ -679,14 +691,24 @@ class TrainEngine:
         if not self.dp:
             return
         if self._gsync is None:
-            from .parallel import GradSync
-            self._gsync = GradSync(self.pg)
+            from .parallel import GradSync, ShardedSync
+            self._gsync = ShardedSync(self.L, self.pg) if self.shard else GradSync(self.pg)
         if self._gsync.reset not in p.abort_hooks:
             p.abort_hooks.append(self._gsync.reset)
         lo, hi = self.grad_buckets(which)[stage]
         fp = self.Dp if which == "D" else self.Gp
-        bucket = fp.grad[lo:hi]
         gs = self._gsync
+        if self.shard:
+            # sharded optimizer: this bucket's reduce-scatter -> RMSprop shard -> parameter all-gather chain starts now (side
+            # stream); the last bucket also does the step's bookkeeping and joins every chain
+            lr, gscale = self.lr, self.gscale
+            if stage < 2:
+                p.host(lambda: gs.start(fp.flat, fp.grad, fp.sq, lo, hi, lr, gscale), gs.capturable)
+            else:
+                st = tuple(st_arg) if st_arg is not None else (0, 0, 0)
+                p.host(lambda: (gs.start(fp.flat, fp.grad, fp.sq, lo, hi, lr, gscale, st), gs.finish()), gs.capturable)
+            return
+        bucket = fp.grad[lo:hi]
         if stage < 2:
             p.host(lambda: gs.start(bucket), gs.capturable)
         else:
@@ -700,8 +722,8 @@ class TrainEngine:
         o, n = self.Gp.offsets, self.Gp.numel
         return [(o["model.8.weight"], n), (o["model.5.weight"], o["model.8.weight"]), (0, o["model.5.weight"])]
 
-    def _grad_sync_hook(self, p: Plan, which: str):
-        self._grad_bucket_hook(p, which, 2)
+    def _grad_sync_hook(self, p: Plan, which: str, st_arg=None):
+        self._grad_bucket_hook(p, which, 2, st_arg)
 
     def _observer_forward(self, p: Plan):
         b = self.buf
@@ -919,8 +941,9 @@ class TrainEngine:
                ldp=G.ld["model.0.weight"])
         if self.overlap:
             p.join()
-        self._grad_sync_hook(p, "G")
-        self._optimizer(p, G, False, st if fast else 0, self._rng_inc() if fast else 0, 0)
+        g_st = (st if fast else 0, self._rng_inc() if fast else 0, 0)
+        self._grad_sync_hook(p, "G", g_st)
+        self._optimizer(p, G, False, *g_st)
         return p
 
     def _bn_bwd(self, p: Plan, s: Slabs, i: int, lin: str, bn: str, n: int):

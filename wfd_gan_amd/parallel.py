@@ -169,6 +169,93 @@ class GradSync:
         self.pending.clear()
 
 
+class ShardedSync:
+    """Data-parallel optimizer step without the full-size flat pass (round 3): per gradient bucket, in the order the backward
+    completes them,
+
+        reduce-scatter of the bucket's gradients (sum)  ->  RMSprop on this rank's 1/world shard  ->  all-gather of the
+        bucket's updated parameters
+
+    instead of all-reduce of the gradients followed by RMSprop over the whole buffer on every rank.  The bytes on the wire
+    are the same (an all-reduce IS a reduce-scatter plus an all-gather), the optimizer pass is world times smaller, every
+    element is reduced exactly once (on its owner) and then copied, so the replicas stay bit-identical by construction.
+    Each bucket's chain runs on a SIDE stream that forks from the caller's stream when the bucket's gradients are final and
+    is joined by ``finish()`` at the end of the step, so an early bucket's chain overlaps the rest of the backward; under
+    HIP-graph capture the fork / join become graph edges and the RCCL calls graph nodes, as in GradSync.  Both collectives run
+    in place (RCCL's documented in-place forms: recvbuff = sendbuff + rank * count and sendbuff = recvbuff + rank * count),
+    so a bucket's length must be a multiple of the world size (engine.FlatParams pads the bucket starts).
+    Safe because a bucket's parameters are dead for the rest of the step once its gradients are final: the launch that
+    produces a layer's weight gradient is also the last reader of that layer's weights (engine._build_d_rest / _build_g_plan).
+    gloo (test rigs, ranks sharing a GPU): the same arithmetic staged through the host on the caller's stream."""
+
+    def __init__(self, lib, group=None):
+        self.L = lib
+        self.group = group
+        self.active = dist.is_available() and dist.is_initialized()
+        self.world = dist.get_world_size(group) if self.active else 1
+        self.rank = dist.get_rank(group) if self.active else 0
+        self.staged = self.active and dist.get_backend(group) == "gloo"
+        self.capturable = graph_capturable(group)
+        self.side = None
+        self.forked = False
+        self.pending = []           # (interface parity with GradSync: nothing is ever pending on the host)
+
+    def start(self, flat: torch.Tensor, grad: torch.Tensor, sq: torch.Tensor, lo: int, hi: int, lr: float, gscale: float,
+              state=(0, 0, 0)):
+        """The chain for the bucket [lo, hi) of one network's flat (parameter, gradient, square average) buffers.  ``state``:
+        (device pointer, inc0, inc1) of the step's bookkeeping, done by the launch that gets it (the last bucket's)."""
+        n = hi - lo
+        if n % self.world:
+            raise ValueError(f"bucket of {n} elements does not split over {self.world} ranks")
+        sh = n // self.world
+        a = lo + self.rank * sh
+        main = torch.cuda.current_stream(flat.device) if flat.is_cuda else None        # (CPU tensors: host-logic tests)
+
+        def step(stream):
+            self.L.rmsprop(flat.data_ptr() + 4 * a, grad.data_ptr() + 4 * a, sq.data_ptr() + 4 * a, sh, lr, 0.99, 1e-8, gscale,
+                           state[0], state[1], state[2], stream.cuda_stream if stream is not None else 0)
+        if not self.active or self.world == 1 and self.staged:
+            step(main)
+            return
+        if self.staged:
+            h = grad[lo:hi].detach().cpu()
+            dist.all_reduce(h, op=dist.ReduceOp.SUM, group=self.group)
+            grad[a:a + sh].copy_(h[self.rank * sh:(self.rank + 1) * sh])
+            step(main)
+            mine = flat[a:a + sh].detach().cpu()
+            parts = [torch.empty_like(mine) for _ in range(self.world)]
+            dist.all_gather(parts, mine, group=self.group)
+            flat[lo:hi].copy_(torch.cat(parts))
+            return
+        if self.side is None:
+            self.side = torch.cuda.Stream(device=flat.device)
+        side = self.side
+        side.wait_stream(main)                       # fork: everything that produced this bucket's gradients
+        self.forked = True
+        try:
+            with torch.cuda.stream(side):
+                dist.reduce_scatter_tensor(grad[a:a + sh], grad[lo:hi], op=dist.ReduceOp.SUM, group=self.group)
+                step(side)
+                dist.all_gather_into_tensor(flat[lo:hi], flat[a:a + sh], group=self.group)
+        except BaseException:
+            # a collective that refuses (e.g. under stream capture): join the side stream before the error travels on, so
+            # that a capture in progress can still be ended (an unjoined stream invalidates it) and the eager fallback
+            # finds both streams usable
+            main.wait_stream(side)
+            self.forked = False
+            raise
+
+    def finish(self):
+        """Join: the caller's stream waits for every bucket's chain (updated parameters of all ranks in place)."""
+        if self.forked:
+            torch.cuda.current_stream(self.side.device).wait_stream(self.side)
+            self.forked = False
+
+    def reset(self):
+        """A capture that forked the side stream was abandoned (engine._capture_stages' fallback): forget the fork."""
+        self.forked = False
+
+
 def shard_rows(n_rows: int, rank: int, world: int) -> Tuple[int, int]:
     """Contiguous [begin, end) shard of n_rows for this rank; the first n_rows % world ranks get one extra row."""
     base, rem = divmod(n_rows, world)
