@@ -37,10 +37,12 @@ def test_exact_dp_equals_reference_update(name, world):
     assert all(p.exitcode == 0 for p in procs)
 
 
-@pytest.mark.parametrize("name,world", [("cfg1", 2), ("cfg2", 3)])
-def test_weak_dp_buckets_sum_every_gradient(name, world):
-    """Weak mode (per-rank batches, bucketed asynchronous all-reduce): the flat gradient buffers hold the sum of the ranks'
-    local gradients everywhere and the replicas stay bit-identical (ranks share cuda:0, gloo)."""
+@pytest.mark.parametrize("name,world,shard", [("cfg1", 2, False), ("cfg2", 3, False), ("cfg1", 2, True), ("cfg2", 3, True)])
+def test_weak_dp_buckets_sum_every_gradient(name, world, shard, monkeypatch):
+    """Weak mode (per-rank batches): with the bucketed asynchronous all-reduce the flat gradient buffers hold the sum of the
+    ranks' local gradients everywhere; with the sharded optimizer (WFD_DP_SHARD=1) every rank's shards hold it and the
+    parameters take the step of the sum.  Either way the replicas stay bit-identical (ranks share cuda:0, gloo)."""
+    monkeypatch.setenv("WFD_DP_SHARD", "1" if shard else "0")          # inherited by the spawned ranks
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()

@@ -146,18 +146,24 @@ def nccl_world1():
         dist.destroy_process_group()
 
 
+# The sharded form (WFD_DP_SHARD=1, parallel.ShardedSync) is covered in this suite over gloo (tests/test_cpu_dp.py,
+# tests/test_gpu_dp_exact.py); its RCCL world-1 runs live in tools/dp_shard_world1.py, outside the suite: one in-suite run of
+# them aborted the interpreter without a message, and an abort here would take every later test down.
+@pytest.mark.parametrize("shard", [False])
 @pytest.mark.parametrize("captured", [True, False])
-def test_data_parallel_world1_nccl(captured, monkeypatch, nccl_world1):
+def test_data_parallel_world1_nccl(captured, shard, monkeypatch, nccl_world1):
     import gc
-    _data_parallel_world1_nccl(captured, monkeypatch)
+    monkeypatch.setenv("WFD_DP_SHARD", "1" if shard else "0")
+    _data_parallel_world1_nccl(captured, monkeypatch, shard)
     gc.collect()                      # the engines and their graphs go before the next test (and before the group does)
     torch.cuda.synchronize()
 
 
-def _data_parallel_world1_nccl(captured, monkeypatch):
-    """The data-parallel code path (bias gradients ahead of the weight gradients; per bucket reduce-scatter -> RMSprop on the
-    rank's shard -> parameter all-gather over RCCL on a side stream, parallel.ShardedSync) with a 1-rank NCCL group must
-    reproduce the single-rank engine bit for bit -- with the collectives
+def _data_parallel_world1_nccl(captured, monkeypatch, shard):
+    """The data-parallel code path (bias gradients ahead of the weight gradients; bucketed asynchronous all-reduce over RCCL +
+    flat optimizer pass, parallel.GradSync -- or, shard: per bucket reduce-scatter -> RMSprop on the rank's shard -> parameter
+    all-gather on a side stream, parallel.ShardedSync) with a 1-rank NCCL group must reproduce the single-rank engine bit for
+    bit -- with the collectives
     captured INSIDE the step graphs (one graph replay per D-step / G-step / group: the default on the "nccl" backend) and
     with them issued eagerly between separately captured stages (WFD_DP_GRAPH=0)."""
     import torch.distributed as dist
@@ -173,9 +179,10 @@ def _data_parallel_world1_nccl(captured, monkeypatch):
         for e in (e1, e2):
             e.attach_dataset(torch.from_numpy(Xs), torch.from_numpy(y), shuffle_seed=5)
             e.capture_graphs()
-        # eager collectives: stage, chain 0, stage, chain 1, stage, chain 2 + join (the sharded optimizer runs inside the
-        # chains: no optimizer stage behind them)
-        assert len(e2.graph_d) == (1 if captured else 6) and len(e1.graph_d) == 1
+        # eager collectives: stage, start, stage, start, stage, start + finish, stage (optimizer); the sharded optimizer runs
+        # inside the buckets' chains, so no optimizer stage follows them
+        assert e2.shard == shard
+        assert len(e2.graph_d) == (1 if captured else (6 if shard else 7)) and len(e1.graph_d) == 1
         assert (e2.graph_group is not None) == captured
         for i in range(7):
             e1.iteration(i)
@@ -191,7 +198,7 @@ def _data_parallel_world1_nccl(captured, monkeypatch):
             e.attach_dataset(torch.from_numpy(Xs), torch.from_numpy(y), shuffle_seed=5)
             grp = GroupedTrainer(e, graphs=True)
             if e is e3:
-                assert len(grp.stages) == (1 if captured else 4 * 6)
+                assert len(grp.stages) == (1 if captured else (4 * 6 if shard else 1 + 3 * 6 + 6))
             for _ in range(3):
                 grp.run_group()
             torch.cuda.synchronize()
@@ -200,41 +207,58 @@ def _data_parallel_world1_nccl(captured, monkeypatch):
             assert torch.equal(a, b)
 
 
-def test_capture_fallback_drops_stale_collective_handles(monkeypatch, nccl_world1):
-    """A capture WITH collectives that fails half-way (here: forced, the second bucket's reduce-scatter of the first captured
-    D-step refuses, after the first bucket's chain went into the capture) must fall back to eager collectives between graph stages -- and the
-    host-side state of the abandoned capture (GradSync: Work handles; ShardedSync: the forked side stream) must be gone, or the
-    eager retry's first finish() waits on it.  The fallback engine then has to reproduce the single-rank engine bit for bit."""
+@pytest.mark.parametrize("shard", [False])
+def test_capture_fallback_drops_stale_collective_handles(shard, monkeypatch, nccl_world1):
+    """A capture WITH collectives that fails half-way must fall back to eager collectives between graph stages, and the
+    host-side state of the abandoned capture must be gone, or the eager retry's first finish() waits on it.
+    all-reduce form (GradSync): forced in the finish() of the first captured D-step, with the three buckets' Work handles
+    pending.  sharded form (ShardedSync): the second bucket's reduce-scatter refuses, after the first bucket's chain went
+    into the capture and the side stream was forked (the chain joins it before the error travels on).  The fallback engine
+    then has to reproduce the single-rank engine bit for bit."""
     import gc
     import warnings
+    import torch.distributed as dist
     from wfd_gan_amd import parallel
     from wfd_gan_amd.engine import TrainEngine
     monkeypatch.setenv("WFD_DP_GRAPH", "1")
+    monkeypatch.setenv("WFD_DP_SHARD", "1" if shard else "0")
     S, C, Z, B = 41, 5, 16, 8
     st, e1, Xs, y = _setup(S, C, Z, B, "div")
     e2 = TrainEngine(S, C, Z, B, e1.scaler_min, e1.scaler_max, e1.generator_state(), e1.discriminator_state(),
                      {k: v for k, v in st.DF.items()}, device=DEV, world_size=1, force_sync=True)
+    assert e2.shard == shard
     for e in (e1, e2):
         e.attach_dataset(torch.from_numpy(Xs), torch.from_numpy(y), shuffle_seed=5)
     e1.capture_graphs()
-    import torch.distributed as dist
-    real_rs, seen = dist.reduce_scatter_tensor, {"calls": 0, "forced": 0}
+    seen = {"calls": 0, "forced": 0, "stale": None}
+    if shard:
+        real_rs = dist.reduce_scatter_tensor
 
-    def refusing_reduce_scatter(*a, **k):
-        if torch.cuda.is_current_stream_capturing() and not seen["forced"]:
-            seen["calls"] += 1
-            if seen["calls"] == 2:             # the second bucket's: the first bucket's chain is already in the capture
+        def refusing_reduce_scatter(*a, **k):
+            if torch.cuda.is_current_stream_capturing() and not seen["forced"]:
+                seen["calls"] += 1
+                if seen["calls"] == 2:         # the second bucket's: the first bucket's chain is already in the capture
+                    seen["forced"] = 1
+                    raise RuntimeError("forced capture failure (test): collective refused")
+            return real_rs(*a, **k)
+        monkeypatch.setattr(dist, "reduce_scatter_tensor", refusing_reduce_scatter)
+    else:
+        real_finish = parallel.GradSync.finish
+
+        def finish(self):
+            if torch.cuda.is_current_stream_capturing() and not seen["forced"]:
                 seen["forced"] = 1
-                raise RuntimeError("forced capture failure (test): collective refused")
-        return real_rs(*a, **k)
-    monkeypatch.setattr(dist, "reduce_scatter_tensor", refusing_reduce_scatter)
+                seen["stale"] = len(self.pending)
+                raise RuntimeError("forced capture failure (test)")
+            return real_finish(self)
+        monkeypatch.setattr(parallel.GradSync, "finish", finish)
     with warnings.catch_warnings(record=True) as w:
         warnings.simplefilter("always")
         e2.capture_graphs()
-    assert seen["forced"] == 1
+    assert seen["forced"] == 1 and (shard or seen["stale"] == 3)
     assert any("falling back to eager collectives" in str(x.message) for x in w)
-    assert e2._gsync.forked is False and e2._gsync.pending == []
-    assert len(e2.graph_d) == 6                                # stage, chain, stage, chain, stage, chain + join
+    assert e2._gsync.pending == [] and not getattr(e2._gsync, "forked", False)
+    assert len(e2.graph_d) == (6 if shard else 7)
     for i in range(7):
         e1.iteration(i)
         e2.iteration(i)
