@@ -34,7 +34,7 @@ def _operands(layout, M, N, K, seed):
     return A.to(DEV), lda, B.to(DEV), ldb, ref, g
 
 
-@pytest.mark.parametrize("cfg", [1, 2, 3, 4, 5])
+@pytest.mark.parametrize("cfg", [1, 2, 3, 4, 5, 6])
 @pytest.mark.parametrize("layout", [0, 1])
 @pytest.mark.parametrize("shape", SHAPES)
 def test_wk_raw_and_epilogues(shape, layout, cfg):
@@ -133,7 +133,7 @@ def test_wk_conv8_matches_torch(geom, cfg):
 
 
 @pytest.mark.parametrize("mode", [1, 2])
-@pytest.mark.parametrize("cfg", [1, 2, 3, 4, 5])
+@pytest.mark.parametrize("cfg", [1, 2, 3, 4, 5, 6])
 @pytest.mark.parametrize("layout", [0, 1])
 @pytest.mark.parametrize("shape", [(128, 2048, 1501), (64, 512, 600), (5, 7, 33), (33, 100, 512)])
 def test_wk_bf16_pipe_modes(shape, layout, cfg, mode):

@@ -6,7 +6,7 @@ R=$GRAFT_REPO_ROOT
 for i in $(seq 1 $N); do
   for v in A B; do
     lib=$A; [ $v = B ] && lib=$B
-    WFD_LIB_PATH=$R/$lib timeout -k 10 200 python3 $R/bench.py --steps 300 --warmup 30 --no-cpu-baseline --no-modes --no-sampling "$@" 2>/dev/null \
+    WFD_LIB_PATH=$R/$lib timeout -k 10 200 python3 $R/bench.py --steps 300 --warmup 30 --no-cpu-baseline --no-modes --no-sampling --no-extras "$@" 2>/dev/null \
       | python3 -c "import json,sys; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('$v', '$lib', round(d['value'],1), round(d['roofline']['avg_us_per_launch'],3), d['roofline']['launches_timed'])" || exit 1
   done
 done

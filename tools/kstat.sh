@@ -6,7 +6,7 @@ R=$GRAFT_REPO_ROOT
 cd /tmp && export TMPDIR=/tmp
 for e in "$@"; do export "$e"; done
 rm -rf $R/gpurun_out/kprof_$TAG
-timeout -k 10 200 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/kprof_$TAG -- python3 $R/bench.py --steps 60 --warmup 6 --repeats 1 --no-cpu-baseline --no-sampling --no-modes > $R/gpurun_out/kstat_$TAG.log 2>&1 || { tail -5 $R/gpurun_out/kstat_$TAG.log; exit 1; }
+timeout -k 10 200 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/kprof_$TAG -- python3 $R/bench.py --steps 60 --warmup 6 --repeats 1 --no-cpu-baseline --no-sampling --no-modes --no-extras > $R/gpurun_out/kstat_$TAG.log 2>&1 || { tail -5 $R/gpurun_out/kstat_$TAG.log; exit 1; }
 cp $(ls $R/gpurun_out/kprof_$TAG/*/*kernel_stats.csv | head -1) $R/gpurun_out/kstat_$TAG.csv
 rm -rf $R/gpurun_out/kprof_$TAG
 python3 - <<PY

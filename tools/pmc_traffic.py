@@ -35,7 +35,7 @@ n = sum(v["launches"] for v in g)
 res["_gemm_all"] = dict(launches=n, hbm_bytes_per_launch=sum(v["hbm_bytes_per_launch"] * v["launches"] for v in g) / max(n, 1))
 res["_meta"] = dict(launches=0, hbm_bytes_per_launch=0.0, commit=sys.argv[4] if len(sys.argv) > 4 else "unknown",
                     command="rocprofv3 --pmc FETCH_SIZE | WRITE_SIZE (separate passes) --kernel-trace -- python3 bench.py --steps 12 "
-                            "--warmup 3 --repeats 1 --no-graph --no-cpu-baseline --no-sampling --no-modes")
+                            "--warmup 3 --repeats 1 --no-graph --no-cpu-baseline --no-sampling --no-modes --no-extras")
 json.dump(res, open(sys.argv[3], "w"), indent=1)
 for k, v in res.items():
     print(f"{k:60s} n={v['launches']:5d} hbm/launch={v['hbm_bytes_per_launch']/1e6:8.3f} MB")

@@ -358,9 +358,20 @@ extern "C" int wfd_gemm_f32_stamped(int layout, const float* A, int lda, const f
 namespace {
 #endif
 
+// rgy > 0: a 1-D grid whose index is remapped so that the rgy row tiles of one (column tile, split) land on ONE XCD
+// (workgroups b and b + 8 share an XCD): with a column-tile count that is no multiple of 8 the plain (x, y, z) order puts
+// them on different XCDs and each of their L2s fetches the same weight tile from HBM -- the critic's input gradient
+// (128 x 1401 x 2048: 22 column tiles, 2 row tiles, 11 splits) read 32 MB for a 12.3 MB weight matrix.  Speed only: any
+// placement gives the same result.
 template <bool AKC, bool BKC, int VA, int VB, bool IM2COL, bool NARROW, int EPI>
-__global__ __launch_bounds__(NTHREADS) void gemm_f32_kernel(GemmArgs g) {
+__global__ __launch_bounds__(NTHREADS) void gemm_f32_kernel(GemmArgs g, int rgx, int rgy, int rgz) {
     __shared__ __attribute__((aligned(16))) float lds[4 * TILE_F];
+    if (rgy > 0) {
+        const int id = blockIdx.x, by = (id >> 3) % rgy, t = (id / (8 * rgy)) * 8 + (id & 7);
+        if (t >= rgx * rgz) return;                  // uniform over the workgroup, before any barrier
+        gemm_f32_body<AKC, BKC, VA, VB, IM2COL, NARROW, EPI>(g, lds, t % rgx, by, t / rgx);
+        return;
+    }
     gemm_f32_body<AKC, BKC, VA, VB, IM2COL, NARROW, EPI>(g, lds, blockIdx.x, blockIdx.y, blockIdx.z);
 }
 
@@ -663,10 +674,17 @@ __global__ __launch_bounds__(NTHREADS, WPE) void gemm_f32_rms_persist_kernel(Per
 template <bool AKC, bool BKC, bool IM2COL, bool NARROW, int EPI>
 int launch_gemm2(const GemmArgs& g, int splits, bool va4, bool vb4, hipStream_t st) {
     dim3 grid(NARROW ? cdiv(g.N, 32) : cdiv(g.N, BN), cdiv(g.M, BM), splits), block(NTHREADS);
-    if (va4 && vb4) hipLaunchKernelGGL((gemm_f32_kernel<AKC, BKC, 4, 4, IM2COL, NARROW, EPI>), grid, block, 0, st, g);
-    else if (va4) hipLaunchKernelGGL((gemm_f32_kernel<AKC, BKC, 4, 1, IM2COL, NARROW, EPI>), grid, block, 0, st, g);
-    else if (vb4) hipLaunchKernelGGL((gemm_f32_kernel<AKC, BKC, 1, 4, IM2COL, NARROW, EPI>), grid, block, 0, st, g);
-    else hipLaunchKernelGGL((gemm_f32_kernel<AKC, BKC, 1, 1, IM2COL, NARROW, EPI>), grid, block, 0, st, g);
+    int rgx = 0, rgy = 0, rgz = 0;
+    // (the switch: same-session A/B.  WFD_GEMM_XCD_PAIR=0: plain (x, y, z) grid everywhere)
+    static const int xcd_pair = getenv("WFD_GEMM_XCD_PAIR") ? atoi(getenv("WFD_GEMM_XCD_PAIR")) : 1;
+    if (xcd_pair && grid.y >= 2 && grid.y <= 8 && (grid.x & 7) != 0) {
+        rgx = (int)grid.x; rgy = (int)grid.y; rgz = (int)grid.z;
+        grid = dim3((unsigned)(((rgx * rgz + 7) / 8) * 8 * rgy), 1, 1);
+    }
+    if (va4 && vb4) hipLaunchKernelGGL((gemm_f32_kernel<AKC, BKC, 4, 4, IM2COL, NARROW, EPI>), grid, block, 0, st, g, rgx, rgy, rgz);
+    else if (va4) hipLaunchKernelGGL((gemm_f32_kernel<AKC, BKC, 4, 1, IM2COL, NARROW, EPI>), grid, block, 0, st, g, rgx, rgy, rgz);
+    else if (vb4) hipLaunchKernelGGL((gemm_f32_kernel<AKC, BKC, 1, 4, IM2COL, NARROW, EPI>), grid, block, 0, st, g, rgx, rgy, rgz);
+    else hipLaunchKernelGGL((gemm_f32_kernel<AKC, BKC, 1, 1, IM2COL, NARROW, EPI>), grid, block, 0, st, g, rgx, rgy, rgz);
     WFD_CHECK_LAUNCH();
     return WFD_OK;
 }
@@ -1441,7 +1459,7 @@ int wfd_conv8_wgrad_f32(const float* dY, const float* X, int Bn, int L, int Cin,
     g.ktiles_per_split = cdiv(cdiv(g.K, BK), splits);
     g.convL = L; g.convCin = Cin; g.convPad = 3;
     dim3 grid(cdiv(g.N, BN), cdiv(g.M, BM), splits), block(NTHREADS);
-    hipLaunchKernelGGL((gemm_f32_kernel<false, false, 4, 4, true, false, false>), grid, block, 0, (hipStream_t)stream, g);
+    hipLaunchKernelGGL((gemm_f32_kernel<false, false, 4, 4, true, false, false>), grid, block, 0, (hipStream_t)stream, g, 0, 0, 0);
     WFD_CHECK_LAUNCH();
     return WFD_OK;
 }

@@ -74,7 +74,11 @@ __device__ __forceinline__ void wave_lds_fence() {
 }
 
 // bid: the workgroup's index within ITS product (a launch may carry several products: gemm_wk_multi_kernel)
-template <bool BKC, bool IM2COL, int RT, int CT, int NW, int TERMS>
+// NBUF: LDS buffers per wave.  2: the next chunk is parked beside the one being multiplied.  1: it overwrites it -- legal
+// because the region is private to the wave and LDS serves a wave's instructions in issue order (the chunk's fragment reads
+// precede the next chunk's writes in program order, the wave fence keeps the compiler from swapping them); half the LDS,
+// which is what lets the 48 x 32 tile run with 8 waves (184 KB double-buffered, 92 KB single).
+template <bool BKC, bool IM2COL, int RT, int CT, int NW, int TERMS, int NBUF = 2>
 __device__ __forceinline__ void gemm_wk_body(const WkArgs& g, float* __restrict__ smem, const int bid) {
     constexpr int TM = 16 * RT, TN = 16 * CT;
     constexpr int NA = TM / 8;                       // float4 loads per lane for an A chunk (8 lanes cover a 128-byte row segment)
@@ -83,7 +87,7 @@ __device__ __forceinline__ void gemm_wk_body(const WkArgs& g, float* __restrict_
     constexpr int LDB = BKC ? LDK : TN + 4;          // NN: [k][TN + 4]
     constexpr int B_F = BKC ? TN * LDK : KC * LDB;
     constexpr int BUF_F = A_F + B_F;
-    constexpr int WAVE_F = 2 * BUF_F;                // double buffer, private to the wave
+    constexpr int WAVE_F = NBUF * BUF_F;             // private to the wave
     constexpr int TNP = TN + 4;                      // row stride of the fold image
     static_assert(TM * TNP <= WAVE_F, "fold image must fit the wave's region");
 
@@ -298,8 +302,9 @@ __device__ __forceinline__ void gemm_wk_body(const WkArgs& g, float* __restrict_
     for (int c = c0; c < c1f; ++c) {
         const bool more = c + 1 < c1f;
         if (more) load_fast((c + 1) * KC, ra0, rb0);
-        compute(wsm + cur * BUF_F);
-        if (more) store_chunk(wsm + (cur ^ 1) * BUF_F, ra0, rb0);
+        compute(wsm + (NBUF == 2 ? cur * BUF_F : 0));
+        if constexpr (NBUF == 1) wave_lds_fence();
+        if (more) store_chunk(wsm + (NBUF == 2 ? (cur ^ 1) * BUF_F : 0), ra0, rb0);
         wave_lds_fence();
         cur ^= 1;
     }
@@ -388,12 +393,12 @@ __device__ __forceinline__ void gemm_wk_body(const WkArgs& g, float* __restrict_
     }
 }
 
-template <bool BKC, bool IM2COL, int RT, int CT, int NW, int TERMS>
+template <bool BKC, bool IM2COL, int RT, int CT, int NW, int TERMS, int NBUF = 2>
 __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(1, 2))) void gemm_wk_kernel(WkArgs g) {
     // at most two waves per SIMD are ever resident (LDS: 9-18 KB per wave), so the register allocator may use 256 VGPRs:
     // without the attribute it aims at four waves and spills the prefetched chunk to scratch
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    gemm_wk_body<BKC, IM2COL, RT, CT, NW, TERMS>(g, smem, blockIdx.x);
+    gemm_wk_body<BKC, IM2COL, RT, CT, NW, TERMS, NBUF>(g, smem, blockIdx.x);
 }
 
 // Several INDEPENDENT products of one layout and configuration in one launch (the observer's FC layer beside the critic's
@@ -440,18 +445,18 @@ int launch_wk_multi_cfg(const WkMulti& a, int cfg, hipStream_t st) {
     }
 }
 
-template <bool BKC, bool IM2COL, int RT, int CT, int NW, int TERMS>
+template <bool BKC, bool IM2COL, int RT, int CT, int NW, int TERMS, int NBUF = 2>
 int launch_wk(WkArgs g, hipStream_t st) {
     constexpr int TM = 16 * RT, TN = 16 * CT;
     constexpr int LDB = BKC ? LDK : TN + 4;
-    constexpr int WAVE_F = 2 * (TM * LDK + (BKC ? TN * LDK : KC * LDB));
+    constexpr int WAVE_F = NBUF * (TM * LDK + (BKC ? TN * LDK : KC * LDB));
     const size_t lds = (size_t)NW * WAVE_F * sizeof(float);
-    WFD_LDS_ATTR((gemm_wk_kernel<BKC, IM2COL, RT, CT, NW, TERMS>), lds);
+    WFD_LDS_ATTR((gemm_wk_kernel<BKC, IM2COL, RT, CT, NW, TERMS, NBUF>), lds);
     g.mt = cdiv(g.M, TM);
     g.nt = cdiv(g.N, TN);
     g.cpw = cdiv(cdiv(g.K, KC), NW);
     const int T8 = cdiv((long)g.mt * g.nt, 8);
-    hipLaunchKernelGGL((gemm_wk_kernel<BKC, IM2COL, RT, CT, NW, TERMS>), dim3(8 * T8), dim3(NW * 64), lds, st, g);
+    hipLaunchKernelGGL((gemm_wk_kernel<BKC, IM2COL, RT, CT, NW, TERMS, NBUF>), dim3(8 * T8), dim3(NW * 64), lds, st, g);
     WFD_CHECK_LAUNCH();
     return WFD_OK;
 }
@@ -464,6 +469,9 @@ int launch_wk_cfg2(const WkArgs& g, int cfg, hipStream_t st) {
         case 3: return launch_wk<BKC, IM2COL, 2, 1, 4, TERMS>(g, st);      // 32 x 16 tile, 4 waves
         case 4: return launch_wk<BKC, IM2COL, 2, 1, 8, TERMS>(g, st);      // 32 x 16 tile, 8 waves
         case 5: return launch_wk<BKC, IM2COL, 2, 2, 2, TERMS>(g, st);      // 32 x 32 tile, 2 waves (many tiles, short K)
+        case 6:                                                            // 48 x 32 tile, 8 waves, one LDS buffer per wave
+            if constexpr (!IM2COL) return launch_wk<BKC, false, 3, 2, 8, TERMS, 1>(g, st);
+            return WFD_ERR_ARG;
         default: return WFD_ERR_ARG;
     }
 }
@@ -498,6 +506,14 @@ int wfd_gemm_wk_pick(int layout, int M, int N, int K) {
         return (t16 >= 32 && nchunk >= 16) ? 4 : 0;
     }
     if (M > 256) return 0;
+    // 129 .. 256 rows (the stacked generator forwards of a group: 192; the critic under --penalty gp: 192): with 32-row tiles
+    // the tile count lands just above a multiple of the 256 CUs (192 x 1401: 264 tiles, 192 x 2048: 384) and the launch runs
+    // two rounds of workgroups; 48-row tiles (cfg 6) make it one round of 1.5x the work each
+    if (layout == 0 && M > 128 && nchunk >= 16) {
+        const long t48 = (long)cdiv(M, 48) * cdiv(N, 32);
+        static const int use48 = getenv("WFD_WK_48") ? atoi(getenv("WFD_WK_48")) : 1;       // (the switch: same-session A/B)
+        if (use48 && cdiv(t48, 256) * 48 < cdiv(t32, 256) * 32) return 6;
+    }
     // the critic's input gradient (NN, 128 x 1401 x 2048: 176 tiles, a long K and a consumer -- the penalty row kernel -- that
     // sums slabs anyway): split-K slabs beat every configuration here in the step (tools/wk_tune.py: -0.9 % per group)
     if (layout == 1 && M > 64 && t32 >= 128 && t32 < 192 && nchunk >= 48) return 0;
