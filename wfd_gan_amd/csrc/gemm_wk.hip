@@ -500,6 +500,8 @@ int wfd_gemm_wk_pick(int layout, int M, int N, int K) {
     const int nchunk = cdiv(K, KC);
     if (layout == 3) {
         // conv rows are plentiful: one wave pair per 32 x 32 tile while K is short
+        // (tried in round 3, not kept: 513 .. 768 tiles -- the 64-channel convs at L = 175 -- with ONE LDS buffer per wave so
+        // that three workgroups fit a CU and the launch is a single round: 3551 vs 3565 it/s, same session)
         if (t32 >= 96) return nchunk >= 16 ? 1 : 5;
         // the short, wide convs at the bottom of the observer (few rows, K = 8 Cin >= 1024): 32 x 16 tiles with K over 8 waves
         // instead of split-K slabs + a consumer launch
