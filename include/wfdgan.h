@@ -481,6 +481,38 @@ int wfd_adamax(float* p, const float* g, float* m, float* u, long n, float lr, f
 /* correct[0] += #{rows whose first-maximum logit index equals the label} (src/train_df.py:141-143,153-155) */
 int wfd_argmax_correct(const float* logits, int ldl, int M, int C, const int* labels, int* correct, void* stream);
 
+/* ---- peer-to-peer ("mesh") gradient exchange over xGMI (SURVEY section 8 e) ------------------------------------------------
+ * NO COUNTERPART IN THE REFERENCE (src/mlp_df_wgan_train.py:98-100 picks one device); it replaces what a DistributedDataParallel
+ * wrapper's all-reduce + src/mlp_df_wgan_train.py:230,275 (optimizer.step()) would do.  One process per GPU.  Every rank
+ * allocates an exchange REGION (gradients and, for the fused form, parameters) and a flag block with wfd_mesh_alloc, hands
+ * the 64-byte IPC handles to its peers over any host channel (the Python layer uses torch.distributed's object gather),
+ * maps theirs with wfd_mesh_open and builds a mesh from the W region / flag pointers in rank order (its own entries are
+ * its own allocations).  After that an exchange is ONE kernel launch on the caller's stream (capturable in a HIP graph):
+ * start barrier -> every rank sums its 1/W shard from all ranks in rank order and stores the result to all ranks -> end
+ * barrier (wfd_gan_amd/csrc/mesh.hip).  All ranks must issue the same sequence of exchanges.  Waits are bounded (2 s): a
+ * peer that never arrives is counted in wfd_mesh_status' third word instead of hanging the GPU.
+ * kind 0: region (hipMalloc), 1: flag block (wfd_mesh_flag_bytes() bytes, uncached); both zeroed; handle: 64 bytes out. */
+int wfd_mesh_flag_bytes(void);
+int wfd_mesh_alloc(long bytes, int kind, void** ptr, void* ipc_handle);
+int wfd_mesh_open(const void* ipc_handle, void** ptr);
+int wfd_mesh_close(void* ptr);
+int wfd_mesh_free(void* ptr);
+/* data[p] / flags[p]: rank p's region / flag block as mapped into THIS process, p = 0 .. world-1 (world <= 8); the device
+ * that is current now is the mesh's device for good */
+int wfd_mesh_create(int rank, int world, void* const* data, void* const* flags, long region_floats, void** mesh);
+int wfd_mesh_destroy(void* mesh);
+/* region[off, off + n) <- sum over ranks, in place on every rank, identical bits everywhere (off, n multiples of 4) */
+int wfd_mesh_allreduce_f32(void* mesh, long off, long n, void* stream);
+/* the data-parallel optimizer step as ONE launch: g = gscale * sum over ranks of region[grad_off + i] (rank order), RMSprop
+ * (wfd_rmsprop's arithmetic, same bits) on the OWNER's region[param_off + i] / sq[i], and the updated parameter stored to
+ * every rank's region[param_off + i]; i in [0, n), each element owned by one rank.  sq: this rank's square averages of
+ * the same n elements (local memory, only the owner's shard is touched).  state / inc0 / inc1 as wfd_rmsprop. */
+int wfd_mesh_reduce_rmsprop(void* mesh, long grad_off, long param_off, float* sq, long n, float lr, float alpha, float eps,
+                            float gscale, unsigned long long* state, unsigned long long inc0, unsigned long long inc1,
+                            void* stream);
+/* synchronises the device; out3 = {exchanges completed, 0, waits that timed out} */
+int wfd_mesh_status(void* mesh, long* out3);
+
 #ifdef __cplusplus
 }
 #endif

@@ -80,9 +80,21 @@ def _run(rank, world, name):
     dist.all_gather(both, flat)
     if not all(torch.equal(both[0], t) for t in both[1:]):
         bad.append(f"rank {rank}: replicas diverged (max |d| = {float((both[0] - both[-1]).abs().max()):.3e})")
-    dist.barrier()
-    dist.destroy_process_group()
+    bad += _mesh_report(eng, rank)
+    del eng
+    parallel.shutdown(destroy=True)
     return bad
+
+
+def _mesh_report(eng, rank):
+    """WFD_DP_MESH=1 (the peer-to-peer exchange, parallel.MeshSync): it must be what ran, and no wait may have timed out."""
+    want = os.environ.get("WFD_DP_MESH", "0") == "1"
+    if bool(eng.mesh_dp) != want:
+        return [f"rank {rank}: mesh_dp = {eng.mesh_dp}, WFD_DP_MESH asked for {want}"]
+    if not want:
+        return []
+    done, timeouts = eng._mesh.status()
+    return [] if done > 0 and timeouts == 0 else [f"rank {rank}: mesh exchanges {done}, timed-out waits {timeouts}"]
 
 
 def trainer_worker(rank, world, port, argv, q):
@@ -161,7 +173,22 @@ def _run_weak(rank, world, name):
     for nme, shape in eng.Dp.specs:
         eng.Dp._view(want, nme, shape).copy_(torch.stack(gathered(loc.Dp.g[nme].contiguous())).double().sum(0))
     got = gathered(eng.Dp.grad)
-    if eng.shard:
+    if eng.mesh_dp:
+        # peer-to-peer form: the sum is formed in registers by the owner of each element and never stored; the buffers keep
+        # the LOCAL gradients, and the parameters every rank ends up with are the RMSprop step of their sum
+        summed = torch.stack(got).double().sum(0)
+        err = float((summed - want).abs().max()) / float(want.abs().max())
+        if err > 1e-6:
+            bad.append(f"rank {rank}: the ranks' local critic gradients do not add up to the expected sum ({err:.2e})")
+        g = want.float() / world
+        sq = 0.01 * g * g
+        step = -meta["lr"] * g / (sq.sqrt() + 1e-8)
+        moved = (eng.Dp.flat.cpu() - before.cpu()).double()
+        big = g.abs() > 1e-6 * float(g.abs().max())
+        perr = float((moved - step.double())[big].abs().max())
+        if perr > 1e-3 * 10 * meta["lr"]:
+            bad.append(f"rank {rank}: critic parameters after the mesh step off by {perr:.2e}")
+    elif eng.shard:
         # sharded optimizer: after the reduce-scatter every rank holds the SUM on its own shard of each bucket; the shards
         # of all ranks together tile the buffer exactly, and the parameters every rank ends up with are the RMSprop step of
         # that sum (owner's shard, gathered)
@@ -198,7 +225,7 @@ def _run_weak(rank, world, name):
     eng.d_step()
     torch.cuda.synchronize()
     # (sharded optimizer: gradients and square averages are only kept on the owner's shard; the PARAMETERS must be identical)
-    for nme, t in ((("G params", eng.Gp.flat), ("D params", eng.Dp.flat)) if eng.shard else
+    for nme, t in ((("G params", eng.Gp.flat), ("D params", eng.Dp.flat)) if eng.shard or eng.mesh_dp else
                    (("G grad", eng.Gp.grad), ("D grad", eng.Dp.grad), ("G params", eng.Gp.flat), ("D params", eng.Dp.flat),
                     ("G sq", eng.Gp.sq), ("D sq", eng.Dp.sq))):
         parts = gathered(t)
@@ -206,8 +233,9 @@ def _run_weak(rank, world, name):
             bad.append(f"rank {rank}: {nme} differs between ranks (max |d| = {float((parts[0] - parts[-1]).abs().max()):.3e})")
     if float(eng.Gp.grad.abs().max()) == 0.0:
         bad.append("generator gradient is zero")
-    dist.barrier()
-    dist.destroy_process_group()
+    bad += _mesh_report(eng, rank)
+    del eng, loc
+    parallel.shutdown(destroy=True)
     return bad
 
 

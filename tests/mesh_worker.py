@@ -1,0 +1,116 @@
+"""One rank of the mesh-exchange tests (tests/test_gpu_mesh.py starts WORLD_SIZE of these on the one GPU of the test box:
+the ranks' regions are then mapped between PROCESSES on one device instead of between devices -- same code path, no xGMI).
+Rendezvous and the expected values travel over gloo; the exchange itself is the library's kernel."""
+import json
+import os
+import sys
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from wfd_gan_amd import parallel  # noqa: E402
+from wfd_gan_amd._lib import lib  # noqa: E402
+
+
+def gather_host(t: torch.Tensor, world: int):
+    h = t.detach().cpu().contiguous()
+    if world == 1:
+        return [h]
+    parts = [torch.empty_like(h) for _ in range(world)]
+    dist.all_gather(parts, h)
+    return parts
+
+
+def main():
+    out_path = sys.argv[1]
+    rank, world, _ = parallel.init_from_env("gloo")
+    dev = torch.device("cuda:0")
+    torch.cuda.set_device(dev)
+    L = lib()
+    res = {"rank": rank, "world": world}
+    sizes = [4, 1024, 4 * 7 * 13, 1 << 20, 3074048 + 2048]      # ragged shards (n / 4 not a multiple of world) included
+    N = max(sizes)
+    mesh = parallel.MeshSync(L, 2 * N, dev)
+    grad, par = mesh.view(0, N), mesh.view(N, N)
+    g = torch.Generator(device="cpu").manual_seed(1234 + rank)
+    ok = True
+    # ---- all-reduce, eager, several sizes back to back (flags count up; a second call must not see the first one's state)
+    for n in sizes:
+        x = torch.randn(n, generator=g)
+        grad[:n].copy_(x)
+        torch.cuda.synchronize()
+        parts = gather_host(grad[:n], world)
+        want = parts[0].clone()
+        for q in parts[1:]:
+            want += q                                 # rank order, fp32: what the owner of every element computes
+        L.mesh_allreduce_f32(mesh.mesh, mesh.offset_of(grad), n, torch.cuda.current_stream().cuda_stream)
+        torch.cuda.synchronize()
+        got = grad[:n].cpu()
+        same = bool(torch.equal(got, want))
+        ok &= same
+        res[f"allreduce_{n}"] = same
+    # ---- fused reduce + RMSprop + parameter push vs wfd_rmsprop on the summed gradients
+    n = sizes[-1]
+    p0 = torch.randn(n, generator=torch.Generator().manual_seed(7))            # identical replicas
+    sq0 = torch.rand(n, generator=torch.Generator().manual_seed(8))
+    sq = sq0.to(dev)
+    par[:n].copy_(p0)
+    grad[:n].copy_(torch.randn(n, generator=g))
+    torch.cuda.synchronize()
+    parts = gather_host(grad[:n], world)
+    gsum = parts[0].clone()
+    for q in parts[1:]:
+        gsum += q
+    rp, rg, rs = p0.to(dev), gsum.to(dev), sq0.to(dev)
+    st = torch.cuda.current_stream().cuda_stream
+    L.rmsprop(rp.data_ptr(), rg.data_ptr(), rs.data_ptr(), n, 5e-5, 0.99, 1e-8, 1.0 / world, 0, 0, 0, st)
+    L.mesh_reduce_rmsprop(mesh.mesh, mesh.offset_of(grad), mesh.offset_of(par), sq.data_ptr(), n, 5e-5, 0.99, 1e-8,
+                          1.0 / world, 0, 0, 0, st)
+    torch.cuda.synchronize()
+    res["fused_params_equal_flat_pass"] = bool(torch.equal(par[:n], rp))
+    per = -(-(n // 4) // world) * 4
+    a, b = rank * per, min((rank + 1) * per, n)
+    res["fused_sq_own_shard"] = bool(torch.equal(sq[a:b], rs[a:b]))
+    untouched = torch.cat([sq[:a], sq[b:]]).cpu()
+    res["fused_sq_rest_untouched"] = bool(torch.equal(untouched, torch.cat([sq0[:a], sq0[b:]])))
+    reps = gather_host(par[:n], world)
+    res["replicas_identical"] = all(bool(torch.equal(reps[0], q)) for q in reps[1:])
+    ok &= res["fused_params_equal_flat_pass"] and res["fused_sq_own_shard"] and res["fused_sq_rest_untouched"] \
+        and res["replicas_identical"]
+    # ---- captured in a HIP graph and replayed: the collective number lives on the device, so replays keep counting
+    n = sizes[3]
+    x = torch.randn(n, generator=g)
+    stage = x.to(dev)
+    s = torch.cuda.Stream()
+    s.wait_stream(torch.cuda.current_stream())
+    gr = torch.cuda.CUDAGraph()
+    with torch.cuda.stream(s):
+        with torch.cuda.graph(gr, stream=s, **parallel.graph_capture_kwargs()):
+            grad[:n].copy_(stage)
+            L.mesh_allreduce_f32(mesh.mesh, mesh.offset_of(grad), n, torch.cuda.current_stream().cuda_stream)
+    parts = gather_host(stage, world)
+    want = parts[0].clone()
+    for q in parts[1:]:
+        want += q
+    good = True
+    for _ in range(3):
+        gr.replay()
+        torch.cuda.synchronize()
+        good &= bool(torch.equal(grad[:n].cpu(), want))
+    res["graph_replays"] = good
+    ok &= good
+    done, timeouts = mesh.status()
+    res["exchanges"], res["timeouts"] = done, timeouts
+    ok &= timeouts == 0 and done == len(sizes) + 1 + 3
+    res["ok"] = bool(ok)
+    del gr, grad, par
+    parallel.shutdown()
+    with open(out_path + f".{rank}", "w") as f:
+        json.dump(res, f)
+    return 0 if ok else 1
+
+
+if __name__ == "__main__":
+    sys.exit(main())

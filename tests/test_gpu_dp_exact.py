@@ -21,8 +21,12 @@ def _free_port():
     return p
 
 
-@pytest.mark.parametrize("name,world", [("tiny", 2), ("cfg2", 2), ("cfg2", 4)])
-def test_exact_dp_equals_reference_update(name, world):
+@pytest.mark.parametrize("name,world,mesh", [("tiny", 2, False), ("cfg2", 2, False), ("cfg2", 4, False), ("cfg2", 2, True),
+                                             ("cfg2", 4, True)])
+def test_exact_dp_equals_reference_update(name, world, mesh, monkeypatch):
+    """mesh: the end of every step is the peer-to-peer exchange (WFD_DP_MESH=1: parameters and gradients in regions the
+    ranks map from each other, one launch sums, applies RMSprop on the owner's shard and stores the parameters to all)."""
+    monkeypatch.setenv("WFD_DP_MESH", "1" if mesh else "0")            # inherited by the spawned ranks
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
@@ -37,12 +41,16 @@ def test_exact_dp_equals_reference_update(name, world):
     assert all(p.exitcode == 0 for p in procs)
 
 
-@pytest.mark.parametrize("name,world,shard", [("cfg1", 2, False), ("cfg2", 3, False), ("cfg1", 2, True), ("cfg2", 3, True)])
+@pytest.mark.parametrize("name,world,shard", [("cfg1", 2, False), ("cfg2", 3, False), ("cfg1", 2, True), ("cfg2", 3, True),
+                                              ("cfg1", 2, "mesh"), ("cfg2", 3, "mesh")])
 def test_weak_dp_buckets_sum_every_gradient(name, world, shard, monkeypatch):
     """Weak mode (per-rank batches): with the bucketed asynchronous all-reduce the flat gradient buffers hold the sum of the
     ranks' local gradients everywhere; with the sharded optimizer (WFD_DP_SHARD=1) every rank's shards hold it and the
-    parameters take the step of the sum.  Either way the replicas stay bit-identical (ranks share cuda:0, gloo)."""
-    monkeypatch.setenv("WFD_DP_SHARD", "1" if shard else "0")          # inherited by the spawned ranks
+    parameters take the step of the sum; with the peer-to-peer exchange (WFD_DP_MESH=1) the sum only exists in the owner's
+    registers and the parameters take its step.  In every form the replicas stay bit-identical (ranks share cuda:0; gloo for
+    the first two, for the third only the rendezvous)."""
+    monkeypatch.setenv("WFD_DP_SHARD", "1" if shard is True else "0")          # inherited by the spawned ranks
+    monkeypatch.setenv("WFD_DP_MESH", "1" if shard == "mesh" else "0")
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()

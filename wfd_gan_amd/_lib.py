@@ -68,7 +68,7 @@ class _Lib:
             fn.argtypes = [_ctype(t) for t, _ in args]
             setattr(self, "_raw_" + name, fn)
             if name in ("wfd_version", "wfd_gemm_pick_splits", "wfd_gemm_pick_splits_mode", "wfd_conv8_direct", "wfd_conv8_direct_mode", "wfd_get_gemm_mode",
-                        "wfd_static_scratch_floats", "wfd_gemm_wk_pick"):      # return a value, not a status
+                        "wfd_static_scratch_floats", "wfd_gemm_wk_pick", "wfd_mesh_flag_bytes"):      # return a value, not a status
                 setattr(self, name[4:], fn)
             else:
                 setattr(self, name[4:], self._checked(name, fn))

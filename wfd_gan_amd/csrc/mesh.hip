@@ -1,0 +1,289 @@
+// Peer-to-peer ("mesh") gradient exchange for the data-parallel step (SURVEY section 8 e: "a hand-written peer-to-peer
+// kernel over hipIpcMemHandle-mapped buffers"; the reference has no counterpart: src/mlp_df_wgan_train.py:98-100 picks
+// one device).
+//
+// An MI355X node is a full mesh: every GPU has its own xGMI link to each of the 7 others (7 x ~153 GB/s), so the
+// bandwidth-optimal exchange is not a ring (per-link bound: 2 (W-1)/W n bytes through ONE link) but "every rank owns 1/W of
+// the buffer": rank r PULLS its shard of the gradients from all W ranks over W-1 links at once, sums them in rank order
+// (one owner per element: the result is what every rank gets, bit for bit), and PUSHES the result back over the same
+// links -- (W-1)/W n bytes each way per rank, spread over all links.  Every rank's exchange region is mapped into every
+// other rank's address space once at set-up (hipIpcGetMemHandle / hipIpcOpenMemHandle), so the exchange is ONE plain kernel
+// launch on the step's stream: no host action, no second stream, capturable in the step's HIP graph like any other launch.
+//
+//   (A) start barrier   workgroup 0 raises START[r] in every rank's flag block; every workgroup waits until START[p] of all
+//                       ranks p reached this collective's number in ITS OWN flag block (peers write, the owner polls
+//                       locally).  A rank raises START only when its stream has reached the launch, i.e. when its
+//                       contribution is final and nothing earlier on its stream still reads what the peers will overwrite.
+//   (B) reduce + push   float4 grid-stride over the rank's shard: W loads (one per rank, all issued before the first add),
+//                       sum in rank order, then either the sum itself (all-reduce) or -- fused optimizer form -- RMSprop
+//                       on the owner's parameter / square-average element and the UPDATED PARAMETER, stored to all W ranks.
+//                       An element is read and written by the same thread only, so the exchange is in place.
+//   (C) end barrier     every thread releases its stores at system scope; the rank's last workgroup (a device-scope ticket)
+//                       raises DONE[r] everywhere; every workgroup waits for DONE[p] of all ranks before it exits, so the
+//                       next launch on the stream sees every peer's pushes, and no peer still reads this rank's region.
+//
+// Flags are monotonically increasing collective numbers (no reset, no ABA), one per 128-byte line, in an uncached
+// allocation of their own; all flag traffic uses system-scope release stores / acquire loads.  Every wait is BOUNDED (2 s
+// of the 100 MHz wall clock): a peer that never arrives is counted in the error word and the kernel ends -- no wave can
+// spin for ever.  The collective number lives in device memory (not in a kernel argument), so a captured graph replays it.
+#include "common.h"
+#include <cstring>
+
+namespace {
+
+constexpr int MAXW = 8;
+constexpr int FLAG_WORDS = 32;                                   // one flag per 128-byte line
+constexpr long FLAG_BLOCK_BYTES = 2L * MAXW * FLAG_WORDS * 4;    // START[8] then DONE[8]
+constexpr unsigned long long SPIN_TICKS = 200000000ull;          // 2 s at 100 MHz
+
+struct MeshDev {                 // by-value kernel argument
+    float* data[MAXW];           // rank p's exchange region as mapped into THIS process
+    unsigned* flags[MAXW];       // rank p's flag block as mapped into this process
+    unsigned* local;             // this rank's private words: [0] collectives completed, [1] workgroup ticket, [2] time-outs
+    int rank, world;
+};
+
+struct Mesh {
+    MeshDev d;
+    int device;
+    long region_floats;
+};
+
+__device__ __forceinline__ void st_sys(unsigned* p, unsigned v) {
+    __hip_atomic_store(p, v, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+// polls are relaxed (the flag block is uncached: every load goes to memory); the acquire that orders the data accesses behind
+// a successful wait is ONE system-scope fence after the wait, not a cache invalidate per poll
+__device__ __forceinline__ unsigned ld_sys(const unsigned* p) {
+    return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+
+// until *f has reached collective number e (wrap-safe), at most SPIN_TICKS
+__device__ __forceinline__ bool wait_flag(const unsigned* f, unsigned e) {
+    const unsigned long long t0 = wall_clock64();
+    while ((int)(ld_sys(f) - e) < 0) {
+        if (wall_clock64() - t0 > SPIN_TICKS) return false;
+        __builtin_amdgcn_s_sleep(4);
+    }
+    return true;
+}
+
+struct MeshOpt { long poff; float* sq; float lr, alpha, eps, gscale; unsigned long long* state; unsigned long long inc0, inc1; };
+
+template <int W, bool OPT>
+__global__ __launch_bounds__(256) void mesh_exchange_kernel(MeshDev m, long goff, long n4, MeshOpt o) {
+    __shared__ int s_last;
+    const int tid = threadIdx.x, r = m.rank;
+    const unsigned e = __hip_atomic_load(m.local, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1u;
+    bool ok = true;
+    if constexpr (OPT) {
+        if (o.state && blockIdx.x == 0 && tid == 0) { o.state[0] += o.inc0; o.state[1] += o.inc1; }
+    }
+    // (A)
+    if (blockIdx.x == 0 && tid < W) st_sys(m.flags[tid] + r * FLAG_WORDS, e);
+    if (tid < W) ok = wait_flag(m.flags[r] + tid * FLAG_WORDS, e);
+    __syncthreads();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "");
+    // (B)
+    const long per = (n4 + W - 1) / W;
+    const long a = (long)r * per, b = a + per < n4 ? a + per : n4;
+    const float4* src[W];
+    float4* dst[W];
+#pragma unroll
+    for (int p = 0; p < W; ++p) {
+        src[p] = reinterpret_cast<const float4*>(m.data[p] + goff);
+        dst[p] = reinterpret_cast<float4*>(m.data[p] + (OPT ? o.poff : goff));
+    }
+    for (long i = a + (long)blockIdx.x * 256 + tid; i < b; i += (long)gridDim.x * 256) {
+        float4 v[W];
+#pragma unroll
+        for (int p = 0; p < W; ++p) v[p] = src[p][i];
+        float4 acc = v[0];
+#pragma unroll
+        for (int p = 1; p < W; ++p) { acc.x += v[p].x; acc.y += v[p].y; acc.z += v[p].z; acc.w += v[p].w; }
+        if constexpr (OPT) {
+            float4* sq4 = reinterpret_cast<float4*>(o.sq);
+            float4 pv = dst[r][i], sv = sq4[i];
+            rmsprop_update(pv.x, sv.x, acc.x * o.gscale, o.lr, o.alpha, o.eps);
+            rmsprop_update(pv.y, sv.y, acc.y * o.gscale, o.lr, o.alpha, o.eps);
+            rmsprop_update(pv.z, sv.z, acc.z * o.gscale, o.lr, o.alpha, o.eps);
+            rmsprop_update(pv.w, sv.w, acc.w * o.gscale, o.lr, o.alpha, o.eps);
+            sq4[i] = sv;
+            acc = pv;
+        }
+#pragma unroll
+        for (int p = 0; p < W; ++p) dst[p][i] = acc;
+    }
+    // (C)
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");
+    __syncthreads();
+    if (tid == 0) {
+        const unsigned t = __hip_atomic_fetch_add(m.local + 1, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+        s_last = t == gridDim.x - 1;
+    }
+    __syncthreads();
+    if (s_last) {                // every workgroup of this rank has released its part
+        if (tid < W) st_sys(m.flags[tid] + (MAXW + r) * FLAG_WORDS, e);
+        if (tid == 0) {
+            __hip_atomic_store(m.local + 1, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(m.local, e, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    }
+    if (tid < W) {
+        ok = wait_flag(m.flags[r] + (MAXW + tid) * FLAG_WORDS, e) && ok;
+        if (!ok) __hip_atomic_fetch_add(m.local + 2, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    __syncthreads();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "");
+}
+
+template <bool OPT>
+int launch_mesh(const Mesh* ms, long goff, long n, const MeshOpt& o, hipStream_t st) {
+    const long n4 = n / 4;
+    const int W = ms->d.world;
+    const long per = (n4 + W - 1) / W;
+    long blocks = (per + 255) / 256;
+    if (blocks > 256) blocks = 256;          // one workgroup per CU: all of them resident at once, every wait is reached
+    if (blocks < 1) blocks = 1;
+    const dim3 g((unsigned)blocks), b(256);
+    switch (W) {
+#define WFD_MESH_CASE(w) case w: hipLaunchKernelGGL((mesh_exchange_kernel<w, OPT>), g, b, 0, st, ms->d, goff, n4, o); break;
+        WFD_MESH_CASE(1) WFD_MESH_CASE(2) WFD_MESH_CASE(3) WFD_MESH_CASE(4)
+        WFD_MESH_CASE(5) WFD_MESH_CASE(6) WFD_MESH_CASE(7) WFD_MESH_CASE(8)
+#undef WFD_MESH_CASE
+        default: return WFD_ERR_ARG;
+    }
+    WFD_CHECK_LAUNCH();
+    return WFD_OK;
+}
+
+int check_range(const Mesh* ms, long off, long n) {
+    if (!ms || off < 0 || n <= 0 || (off & 3) || (n & 3) || off + n > ms->region_floats) return WFD_ERR_ARG;
+    return WFD_OK;
+}
+
+int on_mesh_device(const Mesh* ms, void* stream) {
+    int cur = -1;
+    if (hipGetDevice(&cur) != hipSuccess) return WFD_ERR_LAUNCH;
+    if (cur != ms->device) return WFD_ERR_ARG;
+    if (stream) {
+        hipDevice_t sdev = -1;
+        if (hipStreamGetDevice((hipStream_t)stream, &sdev) != hipSuccess) return WFD_ERR_LAUNCH;
+        if ((int)sdev != cur) return WFD_ERR_ARG;
+    }
+    return WFD_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int wfd_mesh_flag_bytes(void) { return (int)FLAG_BLOCK_BYTES; }
+
+int wfd_mesh_alloc(long bytes, int kind, void** ptr, void* ipc_handle) {
+    if (bytes <= 0 || !ptr || !ipc_handle || (kind != 0 && kind != 1)) return WFD_ERR_ARG;
+    void* p = nullptr;
+    hipError_t e;
+    if (kind == 1) {      // flag block: uncached, so that a peer's store is what the owner's next poll reads
+        e = hipExtMallocWithFlags(&p, (size_t)bytes, hipDeviceMallocUncached);
+        if (e != hipSuccess) { (void)hipGetLastError(); e = hipExtMallocWithFlags(&p, (size_t)bytes, hipDeviceMallocFinegrained); }
+    } else {
+        e = hipMalloc(&p, (size_t)bytes);
+    }
+    if (e != hipSuccess || !p) { (void)hipGetLastError(); return WFD_ERR_WORKSPACE; }
+    if (hipMemset(p, 0, (size_t)bytes) != hipSuccess || hipDeviceSynchronize() != hipSuccess ||
+        hipIpcGetMemHandle(reinterpret_cast<hipIpcMemHandle_t*>(ipc_handle), p) != hipSuccess) {
+        (void)hipGetLastError();
+        (void)hipFree(p);
+        return WFD_ERR_LAUNCH;
+    }
+    *ptr = p;
+    return WFD_OK;
+}
+
+int wfd_mesh_open(const void* ipc_handle, void** ptr) {
+    if (!ipc_handle || !ptr) return WFD_ERR_ARG;
+    hipIpcMemHandle_t h;
+    std::memcpy(&h, ipc_handle, sizeof(h));
+    void* p = nullptr;
+    if (hipIpcOpenMemHandle(&p, h, hipIpcMemLazyEnablePeerAccess) != hipSuccess || !p) { (void)hipGetLastError(); return WFD_ERR_LAUNCH; }
+    *ptr = p;
+    return WFD_OK;
+}
+
+int wfd_mesh_close(void* ptr) {
+    if (!ptr) return WFD_ERR_ARG;
+    if (hipIpcCloseMemHandle(ptr) != hipSuccess) { (void)hipGetLastError(); return WFD_ERR_LAUNCH; }
+    return WFD_OK;
+}
+
+int wfd_mesh_free(void* ptr) {
+    if (!ptr) return WFD_ERR_ARG;
+    if (hipFree(ptr) != hipSuccess) { (void)hipGetLastError(); return WFD_ERR_LAUNCH; }
+    return WFD_OK;
+}
+
+int wfd_mesh_create(int rank, int world, void* const* data, void* const* flags, long region_floats, void** mesh) {
+    if (world < 1 || world > MAXW || rank < 0 || rank >= world || !data || !flags || region_floats <= 0 || !mesh) return WFD_ERR_ARG;
+    Mesh* ms = new Mesh{};
+    for (int p = 0; p < world; ++p) {
+        if (!data[p] || !flags[p] || ((uintptr_t)data[p] & 15)) { delete ms; return WFD_ERR_ARG; }
+        ms->d.data[p] = static_cast<float*>(data[p]);
+        ms->d.flags[p] = static_cast<unsigned*>(flags[p]);
+    }
+    ms->d.rank = rank;
+    ms->d.world = world;
+    ms->region_floats = region_floats;
+    if (hipGetDevice(&ms->device) != hipSuccess || hipMalloc((void**)&ms->d.local, 256) != hipSuccess ||
+        hipMemset(ms->d.local, 0, 256) != hipSuccess || hipDeviceSynchronize() != hipSuccess) {
+        (void)hipGetLastError();
+        delete ms;
+        return WFD_ERR_WORKSPACE;
+    }
+    *mesh = ms;
+    return WFD_OK;
+}
+
+int wfd_mesh_destroy(void* mesh) {
+    if (!mesh) return WFD_ERR_ARG;
+    Mesh* ms = static_cast<Mesh*>(mesh);
+    (void)hipFree(ms->d.local);
+    delete ms;
+    return WFD_OK;
+}
+
+int wfd_mesh_allreduce_f32(void* mesh, long off, long n, void* stream) {
+    const Mesh* ms = static_cast<const Mesh*>(mesh);
+    int rc = check_range(ms, off, n);
+    if (rc == WFD_OK) rc = on_mesh_device(ms, stream);
+    if (rc != WFD_OK) return rc;
+    return launch_mesh<false>(ms, off, n, MeshOpt{}, (hipStream_t)stream);
+}
+
+int wfd_mesh_reduce_rmsprop(void* mesh, long grad_off, long param_off, float* sq, long n, float lr, float alpha, float eps,
+                            float gscale, unsigned long long* state, unsigned long long inc0, unsigned long long inc1,
+                            void* stream) {
+    const Mesh* ms = static_cast<const Mesh*>(mesh);
+    int rc = check_range(ms, grad_off, n);
+    if (rc == WFD_OK) rc = check_range(ms, param_off, n);
+    if (rc == WFD_OK) rc = on_mesh_device(ms, stream);
+    if (rc != WFD_OK) return rc;
+    if (!sq || ((uintptr_t)sq & 15)) return WFD_ERR_ARG;
+    // the two ranges must not overlap: a parameter store of one thread would race a gradient load of another
+    if (grad_off < param_off + n && param_off < grad_off + n) return WFD_ERR_ARG;
+    return launch_mesh<true>(ms, grad_off, n, MeshOpt{param_off, sq, lr, alpha, eps, gscale, state, inc0, inc1}, (hipStream_t)stream);
+}
+
+int wfd_mesh_status(void* mesh, long* out3) {
+    if (!mesh || !out3) return WFD_ERR_ARG;
+    const Mesh* ms = static_cast<const Mesh*>(mesh);
+    unsigned w[3] = {0, 0, 0};
+    if (hipDeviceSynchronize() != hipSuccess || hipMemcpy(w, ms->d.local, sizeof(w), hipMemcpyDeviceToHost) != hipSuccess) {
+        (void)hipGetLastError();
+        return WFD_ERR_LAUNCH;
+    }
+    out3[0] = w[0]; out3[1] = w[1]; out3[2] = w[2];
+    return WFD_OK;
+}
+
+}  // extern "C"

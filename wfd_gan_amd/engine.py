@@ -56,24 +56,36 @@ class FlatParams:
     columns).  The pad columns stay zero: their gradient is never written, and RMSprop maps (p=0, g=0, sq=0) to 0.
     ``p[name]`` / ``g[name]`` are views of the logical shape."""
 
-    def __init__(self, specs, device, bucket_starts: Sequence[str] = (), align: int = 4):
-        """bucket_starts / align (data parallel with the sharded optimizer, parallel.ShardedSync): the named tensors -- the
-        first tensor of each gradient bucket -- start at multiples of ``align`` = 4 * world elements and the buffer's length is
-        one too, so that every bucket splits evenly over the ranks into 16-byte aligned shards.  The pad elements stay 0."""
-        self.specs = specs
-        self.offsets: Dict[str, int] = {}
-        self.ld: Dict[str, int] = {}
+    @staticmethod
+    def layout(specs, bucket_starts: Sequence[str] = (), align: int = 4):
+        """(offsets, row strides, number of elements) of the flat buffer."""
+        offsets: Dict[str, int] = {}
+        ld: Dict[str, int] = {}
         off = 0
         for name, shape in specs:
             if name in bucket_starts:
                 off = rup(off, align)
-            self.offsets[name] = off
-            self.ld[name] = rup(shape[-1], 4) if len(shape) == 2 else shape[-1]
-            off += rup(math.prod(shape[:-1]) * self.ld[name], 4)
-        off = rup(off, align)
+            offsets[name] = off
+            ld[name] = rup(shape[-1], 4) if len(shape) == 2 else shape[-1]
+            off += rup(math.prod(shape[:-1]) * ld[name], 4)
+        return offsets, ld, rup(off, align)
+
+    def __init__(self, specs, device, bucket_starts: Sequence[str] = (), align: int = 4, storage=None):
+        """bucket_starts / align (data parallel with the sharded optimizer, parallel.ShardedSync): the named tensors -- the
+        first tensor of each gradient bucket -- start at multiples of ``align`` = 4 * world elements and the buffer's length is
+        one too, so that every bucket splits evenly over the ranks into 16-byte aligned shards.  The pad elements stay 0.
+        storage = (flat, grad): zeroed tensors of ``layout(...)[2]`` elements to use for the parameters and the gradients
+        (the peer-mapped exchange region of parallel.MeshSync) instead of fresh allocations."""
+        self.specs = specs
+        self.offsets, self.ld, off = FlatParams.layout(specs, bucket_starts, align)
         self.numel = off
-        self.flat = torch.zeros(off, dtype=torch.float32, device=device)
-        self.grad = torch.zeros(off, dtype=torch.float32, device=device)
+        if storage is not None:
+            self.flat, self.grad = storage
+            if self.flat.numel() != off or self.grad.numel() != off:
+                raise ValueError("storage does not match the layout")
+        else:
+            self.flat = torch.zeros(off, dtype=torch.float32, device=device)
+            self.grad = torch.zeros(off, dtype=torch.float32, device=device)
         self.sq = torch.zeros(off, dtype=torch.float32, device=device)
         self.p = {n: self._view(self.flat, n, s) for n, s in specs}
         self.g = {n: self._view(self.grad, n, s) for n, s in specs}
@@ -274,6 +286,14 @@ class TrainEngine:
         # collectives are 22.8 MB device copies the all-reduce does not make): 3130 vs 2685 it/s -- the default stays the
         # all-reduce form until a multi-GPU run says otherwise.
         self.shard = self.dp and os.environ.get("WFD_DP_SHARD", "0") == "1"
+        # ... or WFD_DP_MESH=1: the hand-written peer-to-peer exchange (parallel.MeshSync, csrc/mesh.hip): parameters and
+        # gradients live in a region every rank maps, and the data-parallel end of a step is ONE launch (start barrier ->
+        # reduce the rank's shard from all ranks -> RMSprop on the shard -> store the parameters to all ranks -> end barrier).
+        # Validated with ranks sharing one GPU; unmeasured on real links, hence opt-in too.
+        self.mesh_dp = self.dp and os.environ.get("WFD_DP_MESH", "0") == "1"
+        if self.mesh_dp and self.shard:
+            raise ValueError("WFD_DP_MESH and WFD_DP_SHARD are two forms of the same step: choose one")
+        self._mesh = None
         self._comm = None
         self.nbt = {"model.3": 0, "model.6": 0}
         dev = self.dev
@@ -283,10 +303,24 @@ class TrainEngine:
             # a second engine for another batch size (the ragged last batch of an epoch) on the SAME parameters,
             # optimizer state, BN buffers and packed observer
             self.Gp, self.Dp, self.Gbuf, self.nbt, self.df = share.Gp, share.Dp, share.Gbuf, share.nbt, share.df
+            self._mesh = share._mesh
         else:
             al = 4 * max(1, self.world)
-            self.Gp = FlatParams(G_PARAM_SPECS(S, C, Z), dev, ("model.5.weight", "model.8.weight"), al)
-            self.Dp = FlatParams(D_PARAM_SPECS(S, C), dev, ("model.3.weight", "model.6.weight"), al)
+            g_lay = (G_PARAM_SPECS(S, C, Z), dev, ("model.5.weight", "model.8.weight"), al)
+            d_lay = (D_PARAM_SPECS(S, C), dev, ("model.3.weight", "model.6.weight"), al)
+            g_store = d_store = None
+            if self.mesh_dp:
+                from .parallel import MeshSync
+                nG = rup(FlatParams.layout(g_lay[0], g_lay[2], al)[2], 64)
+                nD = rup(FlatParams.layout(d_lay[0], d_lay[2], al)[2], 64)
+                self._mesh = MeshSync(self.L, 2 * (nG + nD), dev, self.pg)
+                mv = self._mesh.view
+                g_store = (mv(0, nG)[:FlatParams.layout(g_lay[0], g_lay[2], al)[2]],
+                           mv(nG, nG)[:FlatParams.layout(g_lay[0], g_lay[2], al)[2]])
+                d_store = (mv(2 * nG, nD)[:FlatParams.layout(d_lay[0], d_lay[2], al)[2]],
+                           mv(2 * nG + nD, nD)[:FlatParams.layout(d_lay[0], d_lay[2], al)[2]])
+            self.Gp = FlatParams(*g_lay, storage=g_store)
+            self.Dp = FlatParams(*d_lay, storage=d_store)
             self.Gp.load(G_state)
             self.Dp.load(D_state)
             self.Gbuf = {k: G_state[k].detach().to(**f32).clone() for k in G_BUFFER_KEYS}
@@ -624,7 +658,7 @@ class TrainEngine:
         """optimizer.step() (:230, :275): the flat RMSprop pass, or -- the matrices having been updated in their gradients'
         stores -- the vectors only.  Either also advances the device-resident Philox counter / batch cursor."""
         if not fused:
-            if self.shard:          # done shard by shard inside the buckets' chains (_grad_bucket_hook)
+            if self.shard or self.mesh_dp:   # done shard by shard inside the exchange (_grad_bucket_hook)
                 return
             p.add(self.L.rmsprop, ptr(fp.flat), ptr(fp.grad), ptr(fp.sq), fp.numel, self.lr, 0.99, 1e-8, self.gscale,
                   state, inc0, inc1)
@@ -693,6 +727,16 @@ class TrainEngine:
                      2: [W0, b0, W2, b2, BN3] (3.3 MB, end of the step)
         The optimizer waits for all three (stage 2 also finishes)."""
         if not self.dp:
+            return
+        if self.mesh_dp:
+            # peer-to-peer form: nothing per bucket (an in-stream exchange in the middle of the backward would only make the
+            # ranks wait for each other three times); at the end of the step ONE launch sums, updates and redistributes
+            if stage == 2:
+                fp, ms = (self.Dp if which == "D" else self.Gp), self._mesh
+                st = tuple(st_arg) if st_arg is not None else (0, 0, 0)
+                p.add(self.L.mesh_reduce_rmsprop, ms.mesh, ms.offset_of(fp.grad), ms.offset_of(fp.flat), ptr(fp.sq), fp.numel,
+                      self.lr, 0.99, 1e-8, self.gscale, *st)
+                p.keep.append(ms.base)
             return
         if self._gsync is None:
             from .parallel import GradSync, ShardedSync

@@ -49,6 +49,11 @@ def shutdown(destroy: Optional[bool] = None) -> None:
     gc.collect()
     if torch.cuda.is_available():
         torch.cuda.synchronize()
+    for ref in list(_MESHES):               # peer mappings of the mesh exchange go while the ranks can still meet
+        m = ref()
+        if m is not None:
+            m.close()
+    _MESHES.clear()
     if destroy if destroy is not None else _OWN_PG:
         dist.destroy_process_group()
         _OWN_PG = False
@@ -254,6 +259,125 @@ class ShardedSync:
     def reset(self):
         """A capture that forked the side stream was abandoned (engine._capture_stages' fallback): forget the fork."""
         self.forked = False
+
+
+class _Region:
+    """A device allocation of the kernel library seen as a flat fp32 torch tensor (``__cuda_array_interface__``); tensors made
+    from it keep it alive, and it frees the allocation when the last of them is gone."""
+
+    def __init__(self, lib, ptr: int, nfloats: int):
+        self._lib, self.ptr, self.nfloats = lib, int(ptr), int(nfloats)
+        self.__cuda_array_interface__ = {"shape": (self.nfloats,), "typestr": "<f4", "data": (self.ptr, False), "version": 2,
+                                         "strides": None}
+
+    def __del__(self):
+        try:
+            self._lib.mesh_free(self.ptr)
+        except Exception:        # interpreter shutdown: the process is about to release everything anyway
+            pass
+
+
+_MESHES = []        # weak references to the live MeshSync objects (shutdown() closes them before the process group goes)
+
+
+class MeshSync:
+    """Peer-to-peer gradient exchange (opt-in, WFD_DP_MESH=1; include/wfdgan.h ``wfd_mesh_*``, csrc/mesh.hip): every rank's
+    exchange region -- both networks' flat PARAMETER and GRADIENT buffers live in it -- is mapped into every other rank's
+    address space (hipIpcMemHandle), and the data-parallel end of a step is ONE kernel launch on the step's own stream:
+    start barrier -> every rank sums its 1/world shard of the gradients from all ranks (rank order), applies RMSprop to its
+    shard and stores the updated parameters to all ranks -> end barrier.  No host action, no side stream, no separate
+    optimizer pass; a plain launch in the plan, so the step stays one HIP graph on any backend.  torch.distributed is used
+    once, at set-up, to hand the 64-byte IPC handles around (and for the barriers of ``close()``).
+    An MI355X node is a full mesh (a link to each of the 7 peers), which is what this exchange pattern is shaped for; here
+    it could only be run with several ranks sharing ONE GPU (tests), so on real links it is unmeasured."""
+
+    def __init__(self, lib, region_floats: int, device, group=None):
+        import ctypes
+        import weakref
+        self.L, self.group, self.device = lib, group, torch.device(device)
+        self.active = dist.is_available() and dist.is_initialized()
+        self.world = dist.get_world_size(group) if self.active else 1
+        self.rank = dist.get_rank(group) if self.active else 0
+        if self.world > 8:
+            raise ValueError("the mesh exchange serves one node: at most 8 ranks")
+        self.capturable = True
+        self.pending = []
+        self.mesh = None
+        self._opened: List[int] = []
+        n = int(region_floats)
+        with torch.cuda.device(self.device):
+            hd, hf = ctypes.create_string_buffer(64), ctypes.create_string_buffer(64)
+            pd, pf = ctypes.c_void_p(), ctypes.c_void_p()
+            lib.mesh_alloc(4 * n, 0, ctypes.addressof(pd), ctypes.addressof(hd))
+            self.region = _Region(lib, pd.value, n)
+            lib.mesh_alloc(lib.mesh_flag_bytes(), 1, ctypes.addressof(pf), ctypes.addressof(hf))
+            self._flags = pf.value
+            data, flags = [self.region.ptr], [self._flags]
+            if self.world > 1:
+                handles = [None] * self.world
+                dist.all_gather_object(handles, (hd.raw, hf.raw), group=group)
+                data, flags = [], []
+                for r, (a, b) in enumerate(handles):
+                    if r == self.rank:
+                        data.append(self.region.ptr)
+                        flags.append(self._flags)
+                        continue
+                    for h, lst in ((a, data), (b, flags)):
+                        q, hb = ctypes.c_void_p(), ctypes.create_string_buffer(h, 64)
+                        lib.mesh_open(ctypes.addressof(hb), ctypes.addressof(q))
+                        self._opened.append(q.value)
+                        lst.append(q.value)
+            arr_d = (ctypes.c_void_p * self.world)(*data)
+            arr_f = (ctypes.c_void_p * self.world)(*flags)
+            m = ctypes.c_void_p()
+            lib.mesh_create(self.rank, self.world, arr_d, arr_f, n, ctypes.addressof(m))
+            self.mesh = m.value
+            self.base = torch.as_tensor(self.region, device=self.device)
+        if self.base.data_ptr() != self.region.ptr or self.base.numel() != n:
+            raise RuntimeError("exchange region: torch did not wrap the allocation in place")
+        _MESHES.append(weakref.ref(self))
+
+    def view(self, off: int, n: int) -> torch.Tensor:
+        return self.base[off: off + n]
+
+    def offset_of(self, t: torch.Tensor) -> int:
+        d = t.data_ptr() - self.region.ptr
+        if d < 0 or d % 16 or d // 4 + t.numel() > self.region.nfloats:
+            raise ValueError("tensor is not a 16-byte aligned part of the exchange region")
+        return d // 4
+
+    # (interface parity with GradSync / ShardedSync: nothing is ever pending on the host)
+    def finish(self):
+        pass
+
+    def reset(self):
+        pass
+
+    def status(self):
+        """(exchanges completed, waits that timed out); synchronises the device."""
+        import ctypes
+        out = (ctypes.c_long * 3)()
+        self.L.mesh_status(self.mesh, out)
+        return int(out[0]), int(out[2])
+
+    def close(self):
+        """Collective: every rank unmaps its peers' regions, then drops its own mesh.  The region itself is freed when the
+        last tensor made from it is gone.  Call after the engines (and their graphs) are gone: parallel.shutdown() does."""
+        if self.mesh is None:
+            return
+        torch.cuda.synchronize(self.device)
+        if self.active:
+            dist.barrier(self.group)          # nobody is inside an exchange any more
+        with torch.cuda.device(self.device):
+            for q in self._opened:
+                self.L.mesh_close(q)
+            self._opened = []
+            if self.active:
+                dist.barrier(self.group)      # every mapping of this rank's memory is gone
+            self.L.mesh_destroy(self.mesh)
+            self.L.mesh_free(self._flags)
+        self.mesh = None
+        self.base = None
 
 
 def shard_rows(n_rows: int, rank: int, world: int) -> Tuple[int, int]:
