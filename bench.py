@@ -635,6 +635,9 @@ def main():
                        "grouped_generator_forwards": grouped, "length_index_saturated": saturated,
                        "operands": args.operands, "wk_fused_products": bool(args.wk),
                        "dp_code_path_forced": bool(args.force_dp),
+                       # how the ranks' gradients meet: RCCL all-reduce + flat optimizer pass (default), WFD_DP_SHARD=1
+                       # reduce-scatter / shard RMSprop / all-gather, WFD_DP_MESH=1 the library's peer-to-peer launch
+                       "dp_form": (("mesh" if eng.mesh_dp else "shard" if eng.shard else "allreduce") if eng.dp else None),
                        "collectives_in_graph": parallel.graph_capturable(),
                        "optimizer_in_gradient_store": {"critic": bool(eng.fuse_d), "generator": bool(eng.fuse_g)}},
             "roofline": {"bound": "mfma", "achieved": roof["tflops"], "peak": peak, "unit": "TFLOP/s",

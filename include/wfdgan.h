@@ -501,6 +501,9 @@ int wfd_mesh_free(void* ptr);
  * that is current now is the mesh's device for good */
 int wfd_mesh_create(int rank, int world, void* const* data, void* const* flags, long region_floats, void** mesh);
 int wfd_mesh_destroy(void* mesh);
+/* workgroups (1024 threads) an exchange may use, 1 .. 256 (default 128, one per second CU).  Every workgroup of every rank waits
+ * for the peers, so all of them must be resident at once: ranks that SHARE a GPU (test rigs) must split its CUs. */
+int wfd_mesh_set_max_blocks(void* mesh, int max_blocks);
 /* region[off, off + n) <- sum over ranks, in place on every rank, identical bits everywhere (off, n multiples of 4) */
 int wfd_mesh_allreduce_f32(void* mesh, long off, long n, void* stream);
 /* the data-parallel optimizer step as ONE launch: g = gscale * sum over ranks of region[grad_off + i] (rank order), RMSprop

@@ -34,6 +34,8 @@ def main():
     N = max(sizes)
     mesh = parallel.MeshSync(L, 2 * N, dev)
     grad, par = mesh.view(0, N), mesh.view(N, N)
+    res["sharing"] = mesh.sharing
+    ok_share = mesh.sharing == world              # the rig: every rank on the one GPU, and MeshSync must have noticed
     g = torch.Generator(device="cpu").manual_seed(1234 + rank)
     ok = True
     # ---- all-reduce, eager, several sizes back to back (flags count up; a second call must not see the first one's state)
@@ -103,7 +105,7 @@ def main():
     ok &= good
     done, timeouts = mesh.status()
     res["exchanges"], res["timeouts"] = done, timeouts
-    ok &= timeouts == 0 and done == len(sizes) + 1 + 3
+    ok &= timeouts == 0 and done == len(sizes) + 1 + 3 and ok_share
     res["ok"] = bool(ok)
     del gr, grad, par
     parallel.shutdown()

@@ -124,3 +124,18 @@ def test_cli_contract_matches_reference_argparse():
                         del argv[i:i + 2]
                     got = vars(mod.parse_args(argv + [flag, text]))[dest]
                     assert got == want and type(got) is type(want), (script, flag, got)
+
+
+def test_mesh_entry_points_reject_bad_arguments_without_touching_a_gpu():
+    """wfd_mesh_*: the argument checks come before any HIP call (a null mesh, more than 8 ranks, a rank outside the world)."""
+    import ctypes
+    from wfd_gan_amd._lib import lib
+    L = lib()
+    assert L.mesh_flag_bytes() == 2 * 8 * 128
+    assert L._raw_wfd_mesh_allreduce_f32(None, 0, 4, None) == 1
+    assert L._raw_wfd_mesh_reduce_rmsprop(None, 0, 4, None, 4, 1e-4, 0.99, 1e-8, 1.0, None, 0, 0, None) == 1
+    out = ctypes.c_void_p()
+    one = (ctypes.c_void_p * 1)(16)
+    assert L._raw_wfd_mesh_create(0, 9, one, one, 4, ctypes.addressof(out)) == 1
+    assert L._raw_wfd_mesh_create(2, 2, one, one, 4, ctypes.addressof(out)) == 1
+    assert L._raw_wfd_mesh_set_max_blocks(None, 4) == 1

@@ -98,11 +98,13 @@ def test_exact_mode_single_rank_is_plain_step():
         assert float((x - y).abs().max()) <= 1e-6 * float(x.abs().max())
 
 
-@pytest.mark.parametrize("mode", ["strong", "weak"])
-def test_trainer_cli_two_ranks(tmp_path, mode):
+@pytest.mark.parametrize("mode,mesh", [("strong", False), ("weak", False), ("weak", True), ("strong", True)])
+def test_trainer_cli_two_ranks(tmp_path, mode, mesh, monkeypatch):
     """The trainer under a 2-rank launch: rank 0 writes the reference's artefacts, the per-epoch files hold every
-    rank's generated rows, the ragged tail is split over the ranks."""
+    rank's generated rows, the ragged tail is split over the ranks.  mesh: with the peer-to-peer exchange (WFD_DP_MESH=1;
+    the tail-batch engines share the first engine's mapped region)."""
     import glob
+    monkeypatch.setenv("WFD_DP_MESH", "1" if mesh else "0")            # inherited by the spawned ranks
     import os
     import re
 
@@ -147,10 +149,11 @@ def test_trainer_cli_two_ranks(tmp_path, mode):
     assert len(glob.glob(str(tmp_path / "ds" / "training_*"))) == 1          # only rank 0 made an output directory
 
 
-@pytest.mark.parametrize("mode", ["weak", "strong"])
-def test_bench_two_ranks_share_one_gpu(mode):
+@pytest.mark.parametrize("mode,mesh", [("weak", False), ("strong", False), ("weak", True)])
+def test_bench_two_ranks_share_one_gpu(mode, mesh):
     """bench.py under a 2-rank launch (the driver's N > 1 form), here with both ranks on cuda:0 over gloo: the
-    data-parallel plans, graph stages, bucketed gradient sync and the JSON contract."""
+    data-parallel plans, graph stages, bucketed gradient sync (or, mesh, the peer-to-peer launch: the weak-mode group then
+    stays ONE graph even on this rig, there being no host-side collective left in it) and the JSON contract."""
     import json
     import os
     import subprocess
@@ -160,7 +163,7 @@ def test_bench_two_ranks_share_one_gpu(mode):
     procs = []
     for r in range(2):
         env = dict(os.environ, RANK=str(r), WORLD_SIZE="2", LOCAL_RANK="0", MASTER_ADDR="127.0.0.1",
-                   MASTER_PORT=str(port), WFD_DIST_BACKEND="gloo")
+                   MASTER_PORT=str(port), WFD_DIST_BACKEND="gloo", WFD_DP_MESH="1" if mesh else "0")
         procs.append(subprocess.Popen([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "6",
                                        "--warmup", "3", "--inst", "20", "--no-sampling", "--no-cpu-baseline", "--dp",
                                        mode], env=env, cwd=root, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True))
@@ -170,6 +173,7 @@ def test_bench_two_ranks_share_one_gpu(mode):
     res = json.loads(line)
     assert res["n_gpus"] == 2 and res["scaling"] == mode and res["value"] > 0
     assert res["config"]["global_batch"] == (128 if mode == "weak" else 64)
+    assert res["config"]["dp_form"] == ("mesh" if mesh else "allreduce")
     steps = res["config"]["optimizer_steps_per_s"]
     assert abs(res["value"] - steps * (2 if mode == "weak" else 1)) < 1e-6 * res["value"]
     assert not [ln for ln in outs[1][0].splitlines() if ln.startswith("{")]          # only rank 0 prints

@@ -39,8 +39,10 @@ def run_ranks(world, script, tmp_path, extra_env=None, timeout=240):
                 p.kill()
     res = []
     for r in range(world):
-        assert procs[r].returncode == 0, f"rank {r} failed:\n{logs[r][-3000:]}"
-        res.append(json.load(open(out + f".{r}")))
+        f = out + f".{r}"
+        got = json.load(open(f)) if os.path.exists(f) else None
+        assert procs[r].returncode == 0, f"rank {r} failed: {got}\n{logs[r][-3000:]}"
+        res.append(got)
     return res
 
 

@@ -54,7 +54,7 @@ __device__ __forceinline__ void rmsprop_update(float& p, float& s, float g, floa
     // v_sqrt_f32 / v_rcp_f32 (1 ulp each) instead of the correctly rounded sequences: the update then differs from torch's
     // by a few ulp of the STEP (~1e-7 of lr * g / sqrt(s)), far inside the 1e-3 parity bar and the 1e-4 the optimizer tests
     // state; it takes the update from ~40 to ~12 VALU instructions per element, which is what the weight-gradient launch's
-    // store phase was spending (knock-out: 4.6 of 43.8 us per critic launch; profiles/r03_rms_persist_notes.md).  Every
+    // store phase was spending (knock-out: 4.6 of 43.8 us per critic launch).  Every
     // kernel that applies RMSprop shares this function, so the fused and the flat forms stay bit-identical to each other.
     p = p - (lr * g) * __builtin_amdgcn_rcpf(__builtin_amdgcn_sqrtf(s) + eps);
 #endif

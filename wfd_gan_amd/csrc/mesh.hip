@@ -35,6 +35,9 @@ constexpr int MAXW = 8;
 constexpr int FLAG_WORDS = 32;                                   // one flag per 128-byte line
 constexpr long FLAG_BLOCK_BYTES = 2L * MAXW * FLAG_WORDS * 4;    // START[8] then DONE[8]
 constexpr unsigned long long SPIN_TICKS = 200000000ull;          // 2 s at 100 MHz
+constexpr int MESH_THREADS = 1024;                               // large workgroups: the fences are per workgroup
+constexpr int MESH_MAX_BLOCKS = 256;                             // one per CU: all resident at once (they wait for peers);
+                                                                 // wfd_mesh_set_max_blocks lowers it for ranks sharing a GPU
 
 struct MeshDev {                 // by-value kernel argument
     float* data[MAXW];           // rank p's exchange region as mapped into THIS process
@@ -47,6 +50,7 @@ struct Mesh {
     MeshDev d;
     int device;
     long region_floats;
+    int max_blocks;
 };
 
 __device__ __forceinline__ void st_sys(unsigned* p, unsigned v) {
@@ -70,8 +74,11 @@ __device__ __forceinline__ bool wait_flag(const unsigned* f, unsigned e) {
 
 struct MeshOpt { long poff; float* sq; float lr, alpha, eps, gscale; unsigned long long* state; unsigned long long inc0, inc1; };
 
-template <int W, bool OPT>
-__global__ __launch_bounds__(256) void mesh_exchange_kernel(MeshDev m, long goff, long n4, MeshOpt o) {
+// U: elements (float4) per thread in flight.  The grid is capped (every workgroup must be resident: they wait for peers), so
+// a thread walks its part in several steps, each a full memory round trip; U independent elements per step keep U * W (+ 2)
+// 16-byte loads in flight per thread: U = 4, 2, 1 for W = 1, 2..4, 5..8.
+template <int W, bool OPT, int U>
+__global__ __launch_bounds__(MESH_THREADS) void mesh_exchange_kernel(MeshDev m, long goff, long n4, MeshOpt o) {
     __shared__ int s_last;
     const int tid = threadIdx.x, r = m.rank;
     const unsigned e = __hip_atomic_load(m.local, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1u;
@@ -82,8 +89,10 @@ __global__ __launch_bounds__(256) void mesh_exchange_kernel(MeshDev m, long goff
     // (A)
     if (blockIdx.x == 0 && tid < W) st_sys(m.flags[tid] + r * FLAG_WORDS, e);
     if (tid < W) ok = wait_flag(m.flags[r] + tid * FLAG_WORDS, e);
+    // ONE wave per workgroup acquires at system scope (a cache invalidate; the waves of a workgroup share the CU's caches and
+    // the barrier orders the others behind it): a fence per wave made this phase, not the data, the cost of the launch
+    if (tid < 64) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "");
     __syncthreads();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "");
     // (B)
     const long per = (n4 + W - 1) / W;
     const long a = (long)r * per, b = a + per < n4 ? a + per : n4;
@@ -94,30 +103,44 @@ __global__ __launch_bounds__(256) void mesh_exchange_kernel(MeshDev m, long goff
         src[p] = reinterpret_cast<const float4*>(m.data[p] + goff);
         dst[p] = reinterpret_cast<float4*>(m.data[p] + (OPT ? o.poff : goff));
     }
-    for (long i = a + (long)blockIdx.x * 256 + tid; i < b; i += (long)gridDim.x * 256) {
-        float4 v[W];
+    float4* sq4 = reinterpret_cast<float4*>(o.sq);
+    const long stride = (long)gridDim.x * MESH_THREADS;
+    for (long i0 = a + (long)blockIdx.x * MESH_THREADS + tid; i0 < b; i0 += U * stride) {
+        float4 v[U][W], pv[U], sv[U];
 #pragma unroll
-        for (int p = 0; p < W; ++p) v[p] = src[p][i];
-        float4 acc = v[0];
+        for (int u = 0; u < U; ++u) {
+            const long i = i0 + u * stride;
+            if (i < b) {
 #pragma unroll
-        for (int p = 1; p < W; ++p) { acc.x += v[p].x; acc.y += v[p].y; acc.z += v[p].z; acc.w += v[p].w; }
-        if constexpr (OPT) {
-            float4* sq4 = reinterpret_cast<float4*>(o.sq);
-            float4 pv = dst[r][i], sv = sq4[i];
-            rmsprop_update(pv.x, sv.x, acc.x * o.gscale, o.lr, o.alpha, o.eps);
-            rmsprop_update(pv.y, sv.y, acc.y * o.gscale, o.lr, o.alpha, o.eps);
-            rmsprop_update(pv.z, sv.z, acc.z * o.gscale, o.lr, o.alpha, o.eps);
-            rmsprop_update(pv.w, sv.w, acc.w * o.gscale, o.lr, o.alpha, o.eps);
-            sq4[i] = sv;
-            acc = pv;
+                for (int p = 0; p < W; ++p) v[u][p] = src[p][i];
+                if constexpr (OPT) { pv[u] = dst[r][i]; sv[u] = sq4[i]; }
+            }
         }
 #pragma unroll
-        for (int p = 0; p < W; ++p) dst[p][i] = acc;
+        for (int u = 0; u < U; ++u) {
+            const long i = i0 + u * stride;
+            if (i < b) {
+                float4 acc = v[u][0];
+#pragma unroll
+                for (int p = 1; p < W; ++p) { acc.x += v[u][p].x; acc.y += v[u][p].y; acc.z += v[u][p].z; acc.w += v[u][p].w; }
+                if constexpr (OPT) {
+                    rmsprop_update(pv[u].x, sv[u].x, acc.x * o.gscale, o.lr, o.alpha, o.eps);
+                    rmsprop_update(pv[u].y, sv[u].y, acc.y * o.gscale, o.lr, o.alpha, o.eps);
+                    rmsprop_update(pv[u].z, sv[u].z, acc.z * o.gscale, o.lr, o.alpha, o.eps);
+                    rmsprop_update(pv[u].w, sv[u].w, acc.w * o.gscale, o.lr, o.alpha, o.eps);
+                    sq4[i] = sv[u];
+                    acc = pv[u];
+                }
+#pragma unroll
+                for (int p = 0; p < W; ++p) dst[p][i] = acc;
+            }
+        }
     }
-    // (C)
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");
+    // (C)  the barrier orders every thread's stores before thread 0, which releases them at system scope for the whole
+    // workgroup (ONE cache write-back per workgroup: a release per wave cost ~0.1 ms per launch) and takes the ticket
     __syncthreads();
     if (tid == 0) {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");
         const unsigned t = __hip_atomic_fetch_add(m.local + 1, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
         s_last = t == gridDim.x - 1;
     }
@@ -133,8 +156,7 @@ __global__ __launch_bounds__(256) void mesh_exchange_kernel(MeshDev m, long goff
         ok = wait_flag(m.flags[r] + (MAXW + tid) * FLAG_WORDS, e) && ok;
         if (!ok) __hip_atomic_fetch_add(m.local + 2, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
-    __syncthreads();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "");
+    // (the launch ends here: the next launch on the stream starts with its own acquire and then sees every peer's stores)
 }
 
 template <bool OPT>
@@ -142,17 +164,19 @@ int launch_mesh(const Mesh* ms, long goff, long n, const MeshOpt& o, hipStream_t
     const long n4 = n / 4;
     const int W = ms->d.world;
     const long per = (n4 + W - 1) / W;
-    long blocks = (per + 255) / 256;
-    if (blocks > 256) blocks = 256;          // one workgroup per CU: all of them resident at once, every wait is reached
+    const int U = W == 1 ? 4 : W <= 4 ? 2 : 1;
+    long blocks = (per + (long)MESH_THREADS * U - 1) / ((long)MESH_THREADS * U);
+    if (blocks > ms->max_blocks) blocks = ms->max_blocks;
     if (blocks < 1) blocks = 1;
-    const dim3 g((unsigned)blocks), b(256);
+    const dim3 g((unsigned)blocks), b(MESH_THREADS);
     switch (W) {
-#define WFD_MESH_CASE(w) case w: hipLaunchKernelGGL((mesh_exchange_kernel<w, OPT>), g, b, 0, st, ms->d, goff, n4, o); break;
-        WFD_MESH_CASE(1) WFD_MESH_CASE(2) WFD_MESH_CASE(3) WFD_MESH_CASE(4)
-        WFD_MESH_CASE(5) WFD_MESH_CASE(6) WFD_MESH_CASE(7) WFD_MESH_CASE(8)
+#define WFD_MESH_CASE(w, u) case w: hipLaunchKernelGGL((mesh_exchange_kernel<w, OPT, u>), g, b, 0, st, ms->d, goff, n4, o); break;
+        WFD_MESH_CASE(1, 4) WFD_MESH_CASE(2, 2) WFD_MESH_CASE(3, 2) WFD_MESH_CASE(4, 2)
+        WFD_MESH_CASE(5, 1) WFD_MESH_CASE(6, 1) WFD_MESH_CASE(7, 1) WFD_MESH_CASE(8, 1)
 #undef WFD_MESH_CASE
         default: return WFD_ERR_ARG;
     }
+    (void)U;
     WFD_CHECK_LAUNCH();
     return WFD_OK;
 }
@@ -234,6 +258,7 @@ int wfd_mesh_create(int rank, int world, void* const* data, void* const* flags, 
     ms->d.rank = rank;
     ms->d.world = world;
     ms->region_floats = region_floats;
+    ms->max_blocks = MESH_MAX_BLOCKS / 2;       // measured at world 1: 64 / 128 / 256 workgroups -> 2892 / 2924 / 2849 it/s
     if (hipGetDevice(&ms->device) != hipSuccess || hipMalloc((void**)&ms->d.local, 256) != hipSuccess ||
         hipMemset(ms->d.local, 0, 256) != hipSuccess || hipDeviceSynchronize() != hipSuccess) {
         (void)hipGetLastError();
@@ -241,6 +266,12 @@ int wfd_mesh_create(int rank, int world, void* const* data, void* const* flags, 
         return WFD_ERR_WORKSPACE;
     }
     *mesh = ms;
+    return WFD_OK;
+}
+
+int wfd_mesh_set_max_blocks(void* mesh, int max_blocks) {
+    if (!mesh || max_blocks < 1 || max_blocks > MESH_MAX_BLOCKS) return WFD_ERR_ARG;
+    static_cast<Mesh*>(mesh)->max_blocks = max_blocks;
     return WFD_OK;
 }
 

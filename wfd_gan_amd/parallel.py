@@ -333,9 +333,28 @@ class MeshSync:
             lib.mesh_create(self.rank, self.world, arr_d, arr_f, n, ctypes.addressof(m))
             self.mesh = m.value
             self.base = torch.as_tensor(self.region, device=self.device)
+            # every workgroup of an exchange waits for the peers, so all workgroups of all ranks on one GPU must be resident
+            # together: ranks that share a GPU (test rigs) split the library's default of 128 workgroups
+            sharing = self._ranks_on_my_gpu()
+            blocks = int(os.environ.get("WFD_MESH_BLOCKS", "0")) or 128 // sharing
+            lib.mesh_set_max_blocks(self.mesh, max(1, min(256, blocks)))
+            self.sharing = sharing
         if self.base.data_ptr() != self.region.ptr or self.base.numel() != n:
             raise RuntimeError("exchange region: torch did not wrap the allocation in place")
         _MESHES.append(weakref.ref(self))
+
+    def _ranks_on_my_gpu(self) -> int:
+        if self.world == 1:
+            return 1
+        import socket
+        pr = torch.cuda.get_device_properties(self.device)
+        ident = getattr(pr, "uuid", None) or getattr(pr, "pci_bus_id", None)
+        mine = (socket.gethostname(), str(ident)) if ident is not None else None
+        allids = [None] * self.world
+        dist.all_gather_object(allids, mine, group=self.group)
+        if any(x is None for x in allids):
+            return self.world             # the GPU cannot be identified: assume the worst
+        return sum(1 for x in allids if x == mine)
 
     def view(self, off: int, n: int) -> torch.Tensor:
         return self.base[off: off + n]
