@@ -25,7 +25,8 @@ int wfd_version(void);
 
 /* ---- dense contractions (fp32 MFMA, exact f32 products) ------------------------------------------------ */
 
-/* Operand mode of every contraction entry point below (process-wide; read when a launch is issued or captured):
+/* Operand mode of every contraction entry point below (per HOST THREAD, so threads driving plans of different modes do
+ * not race; default 0 in every thread; read when a launch is issued or captured):
  *   0  f32-input MFMA, exact f32 products -- the parity path and the default;
  *   1  "bf16":   fp32 data converted to bf16 on its way into LDS, bf16 MFMA, fp32 accumulate (BASELINE config 4);
  *   2  "bf16x3": x = hi + lo split into two bf16, product = hi*hi + hi*lo + lo*hi on the bf16 pipe (products carry

@@ -139,3 +139,29 @@ def test_mesh_entry_points_reject_bad_arguments_without_touching_a_gpu():
     assert L._raw_wfd_mesh_create(0, 9, one, one, 4, ctypes.addressof(out)) == 1
     assert L._raw_wfd_mesh_create(2, 2, one, one, 4, ctypes.addressof(out)) == 1
     assert L._raw_wfd_mesh_set_max_blocks(None, 4) == 1
+
+
+def test_gemm_mode_is_per_host_thread():
+    """wfd_set_gemm_mode is thread-local state: a thread that selects the bf16 pipe does not switch another thread's plans."""
+    import threading
+    from wfd_gan_amd._lib import lib
+    L = lib()
+    assert L.get_gemm_mode() == 0
+    seen = {}
+    go, done = threading.Event(), threading.Event()
+
+    def other():
+        seen["start"] = L.get_gemm_mode()
+        L.set_gemm_mode(2)
+        go.set()
+        done.wait(10)
+        seen["end"] = L.get_gemm_mode()
+    t = threading.Thread(target=other)
+    t.start()
+    assert go.wait(10)
+    assert L.get_gemm_mode() == 0                 # the other thread's choice is not ours
+    L.set_gemm_mode(1)
+    done.set()
+    t.join(10)
+    assert seen == {"start": 0, "end": 2} and L.get_gemm_mode() == 1
+    L.set_gemm_mode(0)

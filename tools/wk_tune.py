@@ -3,7 +3,7 @@
 group of the config-2 step, each candidate timed as the WHOLE step (graph replay of 50 groups) in the same process, because
 isolated per-kernel timings (tools/wk_bench.py) mispredict the step (cold weights, neighbours).  GPU only.
 
-    python tools/wk_tune.py [--operands f32] [--min-gain 0.003]
+    python tools/wk_tune.py [--operands f32] [--penalty div|gp] [--min-gain 0.003]
 """
 import argparse, json, os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -16,9 +16,10 @@ ap = argparse.ArgumentParser()
 ap.add_argument("--operands", default="f32")
 ap.add_argument("--min-gain", type=float, default=0.003)
 ap.add_argument("--groups", type=int, default=60)
+ap.add_argument("--penalty", default="div", choices=["div", "gp"])
 ap.add_argument("--out", default="gpurun_out/wk_tune.json")
 a = ap.parse_args()
-args = argparse.Namespace(seq_len=1401, classes=100, latent_dim=500, batch=64, inst=1000, penalty="div", overlap=0, dp="weak",
+args = argparse.Namespace(seq_len=1401, classes=100, latent_dim=500, batch=64, inst=1000, penalty=a.penalty, overlap=0, dp="weak",
                           operands=a.operands, fuse_opt="1", wk=1, force_dp=False)
 dev = torch.device("cuda:0")
 mode = {"f32": 0, "bf16": 1, "bf16x3": 2}[a.operands]
@@ -65,7 +66,7 @@ from wfd_gan_amd._lib import lib
 Lb = lib()
 for s in uniq:
     pick = Lb.gemm_wk_pick(*s)
-    cands = [c for c in ((1, 5, 3, 4, 0) if s[0] == 3 else (1, 2, 3, 4, 5, 0)) if c != pick]
+    cands = [c for c in ((1, 5, 3, 4, 0) if s[0] == 3 else (1, 2, 3, 4, 5, 6, 0)) if c != pick]
     res = {}
     for c in cands:
         P.WK_OVERRIDE[s] = c

@@ -1044,8 +1044,8 @@ inline bool operands_fit(int layout, int M, int N, int K, int lda, int ldb) {
 }
 
 // operand mode of the contraction entry points: 0 = f32-input MFMA (exact f32 products, the parity path),
-// 1 = bf16 operands, 2 = split-bf16 x3 (gemm_mx.hip).  Process-wide; read when a launch is issued (or captured).
-int g_gemm_mode = 0;
+// 1 = bf16 operands, 2 = split-bf16 x3 (gemm_mx.hip).  Read when a launch is issued (or captured).
+thread_local int g_gemm_mode = 0;      // per host thread: two threads driving plans of different modes do not race
 
 }  // namespace
 
