@@ -514,6 +514,14 @@ int wfd_mesh_allreduce_f32(void* mesh, long off, long n, void* stream);
 int wfd_mesh_reduce_rmsprop(void* mesh, long grad_off, long param_off, float* sq, long n, float lr, float alpha, float eps,
                             float gscale, unsigned long long* state, unsigned long long inc0, unsigned long long inc1,
                             void* stream);
+/* the small exchanges of the exact (global-batch, SyncBN) mode, one-shot (every rank reads all ranks' vectors and forms the
+ * result itself, in rank order; in place; n <= 1024 * max_blocks):
+ *   region[off, off + n) <- sum over ranks                                       (BatchNorm backward sums, selected-row count)
+ *   (mean, M2) of equal row shards -> the pair over all rows, Chan et al.:  mean = sum_p mean_p / W,
+ *   M2 = sum_p M2_p + rows_per_rank * sum_p (mean_p - mean)^2              (train-mode BatchNorm1d over the global batch,
+ *                                                                            src/model.py:23 under a batch split) */
+int wfd_mesh_allreduce_small(void* mesh, long off, int n, void* stream);
+int wfd_mesh_bn_combine(void* mesh, long mean_off, long m2_off, int n, float rows_per_rank, void* stream);
 /* synchronises the device; out3 = {exchanges completed, 0, waits that timed out} */
 int wfd_mesh_status(void* mesh, long* out3);
 

@@ -94,7 +94,13 @@ def _mesh_report(eng, rank):
     if not want:
         return []
     done, timeouts = eng._mesh.status()
-    return [] if done > 0 and timeouts == 0 else [f"rank {rank}: mesh exchanges {done}, timed-out waits {timeouts}"]
+    bad = [] if done > 0 and timeouts == 0 else [f"rank {rank}: mesh exchanges {done}, timed-out waits {timeouts}"]
+    # with every exchange a plain launch, no host-staged collective is left to split a step: one stage (= one HIP graph) each,
+    # also on this rig (gloo between the ranks), in the weak AND in the exact mode
+    for nme, pl in (("D-step", eng.plan_d), ("G-step", eng.plan_g)):
+        if len(pl.stages()) != 1:
+            bad.append(f"rank {rank}: the {nme} plan of the mesh form splits into {len(pl.stages())} stages")
+    return bad
 
 
 def trainer_worker(rank, world, port, argv, q):

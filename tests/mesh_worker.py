@@ -53,6 +53,45 @@ def main():
         same = bool(torch.equal(got, want))
         ok &= same
         res[f"allreduce_{n}"] = same
+    # ---- the exact mode's small one-shot exchanges: vectors from the region's arena, summed / Chan-combined in rank order
+    st = torch.cuda.current_stream().cuda_stream
+    n_small = 0
+    for n in (2, 1000, 4096):
+        v = mesh.alloc_small(n)
+        v.copy_(torch.randn(n, generator=g))
+        torch.cuda.synchronize()
+        parts = gather_host(v, world)
+        want = parts[0].clone()
+        for q in parts[1:]:
+            want += q
+        L.mesh_allreduce_small(mesh.mesh, mesh.offset_of(v), n, st)
+        torch.cuda.synchronize()
+        same = bool(torch.equal(v.cpu(), want))
+        res[f"small_sum_{n}"] = same
+        ok &= same
+        n_small += 1
+    n, rows = 2048, 8.0
+    mean, m2 = mesh.alloc_small(n), mesh.alloc_small(n)
+    mean.copy_(torch.randn(n, generator=g))
+    m2.copy_(torch.rand(n, generator=g) * 5)
+    torch.cuda.synchronize()
+    pm, pq = gather_host(mean, world), gather_host(m2, world)
+    tot = pm[0].clone()
+    for q in pm[1:]:
+        tot += q
+    mu = tot / float(world)
+    sm, sd = pq[0].clone(), (pm[0] - mu) * (pm[0] - mu)
+    for a_, b_ in zip(pm[1:], pq[1:]):
+        sm += b_
+        sd += (a_ - mu) * (a_ - mu)
+    want_m2 = sm + rows * sd
+    L.mesh_bn_combine(mesh.mesh, mesh.offset_of(mean), mesh.offset_of(m2), n, rows, st)
+    torch.cuda.synchronize()
+    res["bn_combine_mean"] = bool(torch.equal(mean.cpu(), mu))
+    res["bn_combine_m2"] = bool(torch.allclose(m2.cpu(), want_m2, rtol=1e-6, atol=0))
+    res["bn_combine_m2_bits"] = bool(torch.equal(m2.cpu(), want_m2))
+    ok &= res["bn_combine_mean"] and res["bn_combine_m2"]
+    n_small += 1
     # ---- fused reduce + RMSprop + parameter push vs wfd_rmsprop on the summed gradients
     n = sizes[-1]
     p0 = torch.randn(n, generator=torch.Generator().manual_seed(7))            # identical replicas
@@ -105,7 +144,7 @@ def main():
     ok &= good
     done, timeouts = mesh.status()
     res["exchanges"], res["timeouts"] = done, timeouts
-    ok &= timeouts == 0 and done == len(sizes) + 1 + 3 and ok_share
+    ok &= timeouts == 0 and done == len(sizes) + n_small + 1 + 3 and ok_share
     res["ok"] = bool(ok)
     del gr, grad, par
     parallel.shutdown()

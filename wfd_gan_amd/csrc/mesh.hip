@@ -159,6 +159,87 @@ __global__ __launch_bounds__(MESH_THREADS) void mesh_exchange_kernel(MeshDev m, 
     // (the launch ends here: the next launch on the stream starts with its own acquire and then sees every peer's stores)
 }
 
+// Small exchanges of the exact (global-batch) mode -- BatchNorm statistics, BatchNorm backward sums, the selected-row count:
+// a few thousand floats, latency-bound, so ONE-shot: after the start barrier every rank reads the vector of ALL ranks and
+// forms the result itself, in rank order (identical bits everywhere); the end barrier then tells every rank that its
+// source has been read, and only then does it overwrite it with the result (in place).  No stores to peers at all.
+//   MODE 0  x[j] <- sum_p x_p[j]
+//   MODE 1  (mean[j], M2[j]) of equal-sized row shards -> the pair over all rows (Chan et al.'s update, what
+//           parallel.Comm.combine_bn_stats_ computes from an all-gather): mean = sum_p mean_p / W,
+//           M2 = sum_p M2_p + rows * sum_p (mean_p - mean)^2
+template <int W, int MODE>
+__global__ __launch_bounds__(MESH_THREADS) void mesh_small_kernel(MeshDev m, long off0, long off1, int n, float rows) {
+    __shared__ int s_last;
+    const int tid = threadIdx.x, r = m.rank;
+    const unsigned e = __hip_atomic_load(m.local, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1u;
+    bool ok = true;
+    if (blockIdx.x == 0 && tid < W) st_sys(m.flags[tid] + r * FLAG_WORDS, e);
+    if (tid < W) ok = wait_flag(m.flags[r] + tid * FLAG_WORDS, e);
+    if (tid < 64) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "");
+    __syncthreads();
+    const int j = blockIdx.x * MESH_THREADS + tid;
+    float r0 = 0.f, r1 = 0.f;
+    if (j < n) {
+#pragma clang fp contract(off)
+        float a[W], b[W];
+#pragma unroll
+        for (int p = 0; p < W; ++p) {
+            a[p] = m.data[p][off0 + j];
+            if constexpr (MODE == 1) b[p] = m.data[p][off1 + j];
+        }
+        r0 = a[0];
+#pragma unroll
+        for (int p = 1; p < W; ++p) r0 += a[p];
+        if constexpr (MODE == 1) {
+            const float mu = r0 / (float)W;
+            float sm = b[0], sd = (a[0] - mu) * (a[0] - mu);
+#pragma unroll
+            for (int p = 1; p < W; ++p) { sm += b[p]; sd += (a[p] - mu) * (a[p] - mu); }
+            r0 = mu;
+            r1 = sm + rows * sd;
+        }
+    }
+    asm volatile("" ::"v"(r0), "v"(r1));          // the loads have landed before this workgroup reports "read"
+    __syncthreads();
+    if (tid == 0) {
+        const unsigned t = __hip_atomic_fetch_add(m.local + 1, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+        s_last = t == gridDim.x - 1;
+    }
+    __syncthreads();
+    if (s_last) {
+        if (tid < W) st_sys(m.flags[tid] + (MAXW + r) * FLAG_WORDS, e);
+        if (tid == 0) {
+            __hip_atomic_store(m.local + 1, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(m.local, e, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    }
+    if (tid < W) {
+        ok = wait_flag(m.flags[r] + (MAXW + tid) * FLAG_WORDS, e) && ok;
+        if (!ok) __hip_atomic_fetch_add(m.local + 2, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    __syncthreads();                              // every rank has read this rank's source: now it may be overwritten
+    if (j < n) {
+        m.data[r][off0 + j] = r0;
+        if constexpr (MODE == 1) m.data[r][off1 + j] = r1;
+    }
+}
+
+template <int MODE>
+int launch_small(const Mesh* ms, long off0, long off1, int n, float rows, hipStream_t st) {
+    const int blocks = (n + MESH_THREADS - 1) / MESH_THREADS;
+    if (blocks > ms->max_blocks) return WFD_ERR_ARG;          // (all workgroups must be resident: this form is for small vectors)
+    const dim3 g((unsigned)blocks), b(MESH_THREADS);
+    switch (ms->d.world) {
+#define WFD_MESH_CASE(w) case w: hipLaunchKernelGGL((mesh_small_kernel<w, MODE>), g, b, 0, st, ms->d, off0, off1, n, rows); break;
+        WFD_MESH_CASE(1) WFD_MESH_CASE(2) WFD_MESH_CASE(3) WFD_MESH_CASE(4)
+        WFD_MESH_CASE(5) WFD_MESH_CASE(6) WFD_MESH_CASE(7) WFD_MESH_CASE(8)
+#undef WFD_MESH_CASE
+        default: return WFD_ERR_ARG;
+    }
+    WFD_CHECK_LAUNCH();
+    return WFD_OK;
+}
+
 template <bool OPT>
 int launch_mesh(const Mesh* ms, long goff, long n, const MeshOpt& o, hipStream_t st) {
     const long n4 = n / 4;
@@ -303,6 +384,24 @@ int wfd_mesh_reduce_rmsprop(void* mesh, long grad_off, long param_off, float* sq
     // the two ranges must not overlap: a parameter store of one thread would race a gradient load of another
     if (grad_off < param_off + n && param_off < grad_off + n) return WFD_ERR_ARG;
     return launch_mesh<true>(ms, grad_off, n, MeshOpt{param_off, sq, lr, alpha, eps, gscale, state, inc0, inc1}, (hipStream_t)stream);
+}
+
+int wfd_mesh_allreduce_small(void* mesh, long off, int n, void* stream) {
+    const Mesh* ms = static_cast<const Mesh*>(mesh);
+    if (!ms || off < 0 || n <= 0 || off + n > ms->region_floats) return WFD_ERR_ARG;
+    const int rc = on_mesh_device(ms, stream);
+    if (rc != WFD_OK) return rc;
+    return launch_small<0>(ms, off, 0, n, 0.f, (hipStream_t)stream);
+}
+
+int wfd_mesh_bn_combine(void* mesh, long mean_off, long m2_off, int n, float rows_per_rank, void* stream) {
+    const Mesh* ms = static_cast<const Mesh*>(mesh);
+    if (!ms || mean_off < 0 || m2_off < 0 || n <= 0 || mean_off + n > ms->region_floats || m2_off + n > ms->region_floats)
+        return WFD_ERR_ARG;
+    if (mean_off < m2_off + n && m2_off < mean_off + n) return WFD_ERR_ARG;
+    const int rc = on_mesh_device(ms, stream);
+    if (rc != WFD_OK) return rc;
+    return launch_small<1>(ms, mean_off, m2_off, n, rows_per_rank, (hipStream_t)stream);
 }
 
 int wfd_mesh_status(void* mesh, long* out3) {

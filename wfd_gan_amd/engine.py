@@ -352,14 +352,17 @@ class TrainEngine:
         b["GPA"] = z(B)                  # WGAN-GP interpolation weights alpha (B,1)
         for nme in ("NDV", "PW", "INVB", "RSELR", "RSELF"):
             b[nme] = z(M)                # constant row weights that turn the loss scalars into column sums
-        b["dstats"], b["gstats"], b["ghead"] = z(8), z(8), z(2)
+        # exact mode over the peer-to-peer exchange: the vectors the ranks combine (BatchNorm statistics, BatchNorm backward
+        # sums, [-sum fv / Bg, #selected]) live in the mapped region, where the peers' launches read them
+        zx = self._mesh.alloc_small if (self.mesh_dp and self.exact) else z
+        b["dstats"], b["gstats"], b["ghead"] = z(8), z(8), zx(2)
         b["dacc"] = share.buf["dacc"] if share is not None else z(4)      # epoch sums live on device
         b["gacc"] = share.buf["gacc"] if share is not None else z(4)
         # generator
         b["GH1"] = z(B, 512)
         for i, n in ((2, 1024), (3, 2048)):
             b[f"GZ{i}"], b[f"GXH{i}"], b[f"GH{i}"] = z(B, n), z(B, n), z(B, n)
-            b[f"mean{i}"], b[f"m2{i}"], b[f"istd{i}"], b[f"bns{i}"] = z(n), z(n), z(n), z(2 * n)
+            b[f"mean{i}"], b[f"m2{i}"], b[f"istd{i}"], b[f"bns{i}"] = zx(n), zx(n), z(n), zx(2 * n)
             b[f"GDZ{i}"] = z(B, n)
         b["GDZ1"] = z(B, 512)
         self.lds4 = rup(S, 4)
@@ -498,6 +501,10 @@ class TrainEngine:
         if not self.exact:
             return
         mean, m2, B = self.buf[f"mean{layer}"], self.buf[f"m2{layer}"], self.B
+        if self.mesh_dp:        # one launch: every rank reads all ranks' pairs and forms the global pair itself
+            ms = self._mesh
+            p.add(self.L.mesh_bn_combine, ms.mesh, ms.offset_of(mean), ms.offset_of(m2), mean.numel(), float(B))
+            return
         p.host(lambda: self.comm.combine_bn_stats_(mean, m2, B), self.comm.capturable)
 
     def _critic_forward(self, p: Plan, X, M: int, mk, H1, H2, H3, D1, D2, D3, V, DL3, DL3s, rowscale):
@@ -880,6 +887,9 @@ class TrainEngine:
         if not self.exact:
             return
         ghead = self.buf["ghead"]
+        if self.mesh_dp:
+            p.add(self.L.mesh_allreduce_small, self._mesh.mesh, self._mesh.offset_of(ghead), 2)
+            return
         p.host(lambda: self.comm.all_reduce_sum_(ghead), self.comm.capturable)
 
     def _build_g_plan(self, fast: bool = False, draw_masks: bool = True, bn_stacked: Optional[Dict[str, torch.Tensor]] = None,
@@ -1011,10 +1021,14 @@ class TrainEngine:
         # is summed over ranks.
         sums, dgam, dbet, w = b[f"bns{i}"], G.g[f"{bn}.weight"], G.g[f"{bn}.bias"], float(self.world)
         p.add(self.L.bn_bwd, *args, 1)
-        p.host(lambda: self.comm.all_reduce_sum_(sums), self.comm.capturable)
+        if self.mesh_dp:
+            p.add(self.L.mesh_allreduce_small, self._mesh.mesh, self._mesh.offset_of(sums), sums.numel())
+        else:
+            p.host(lambda: self.comm.all_reduce_sum_(sums), self.comm.capturable)
         p.add(self.L.bn_bwd, *args, 2)
         if self.world > 1:
-            p.host(lambda: (dgam.div_(w), dbet.div_(w)), self.comm.capturable)
+            # (plain device work on the current stream: inside the graph whenever no host-staged collective splits the plan)
+            p.host(lambda: (dgam.div_(w), dbet.div_(w)), self.comm.capturable or self.mesh_dp)
 
     # ------------------------------------------------------------------------------------------------------
     # inputs

@@ -291,9 +291,13 @@ class MeshSync:
     An MI355X node is a full mesh (a link to each of the 7 peers), which is what this exchange pattern is shaped for; here
     it could only be run with several ranks sharing ONE GPU (tests), so on real links it is unmeasured."""
 
+    ARENA = 1 << 19         # floats at the end of the region for the exact mode's small per-engine vectors (alloc_small)
+
     def __init__(self, lib, region_floats: int, device, group=None):
         import ctypes
         import weakref
+        self._arena_at = int(region_floats)
+        region_floats = int(region_floats) + MeshSync.ARENA
         self.L, self.group, self.device = lib, group, torch.device(device)
         self.active = dist.is_available() and dist.is_initialized()
         self.world = dist.get_world_size(group) if self.active else 1
@@ -358,6 +362,15 @@ class MeshSync:
 
     def view(self, off: int, n: int) -> torch.Tensor:
         return self.base[off: off + n]
+
+    def alloc_small(self, n: int) -> torch.Tensor:
+        """n zeroed floats of the region's arena (256-byte aligned).  Every rank must allocate in the same order: the
+        exchanges address peers' vectors by offset."""
+        a = self._arena_at
+        self._arena_at = a + (n + 63) // 64 * 64
+        if self._arena_at > self.region.nfloats:
+            raise RuntimeError("exchange region: arena of small vectors exhausted")
+        return self.base[a: a + n]
 
     def offset_of(self, t: torch.Tensor) -> int:
         d = t.data_ptr() - self.region.ptr
