@@ -231,6 +231,12 @@ int wfd_gemm_f32_rmsprop_multi_end(const long long* desc, int n, float lr, float
                                    unsigned long long inc1, const float* meanA, const float* m2A, int NA, float* rmeanA,
                                    float* rvarA, const float* meanB, const float* m2B, int NB, float* rmeanB, float* rvarB,
                                    float count, float momentum, int groups, int nupd_last, void* stream);
+/* The data-parallel form of wfd_gemm_f32_rmsprop_multi_colsum: the same weight gradients as ONE launch, but STORED (desc
+ * words 7 / 8 = the gradient matrix and its row stride, word 9 unused) -- the ranks' gradients have to meet before the
+ * optimizer may see them (loss.backward() of src/mlp_df_wgan_train.py:229,274 without :230,275) -- optionally carrying
+ * wfd_colsum_multi(cs_desc, cs_nseg, cs_blocks) in its first workgroups (cs_desc = NULL: none).  Returns 1 when the fast
+ * form does not apply (fewer than 8 tiles, unaligned operands, N <= 32): launch the products one by one then. */
+int wfd_gemm_f32_multi_grad(const long long* desc, int n, const long long* cs_desc, int cs_nseg, int cs_blocks, void* stream);
 
 /* nn.BatchNorm1d(n, eps=0.8) training forward (src/model.py:23), in two halves so that data-parallel ranks can
  * combine (mean, M2) in between: stats writes Z = sumP + bias and the per-column mean / sum of squared deviations;

@@ -476,21 +476,26 @@ __host__ __device__ __forceinline__ void persist_slab(int gy, int gx, int lpr, i
 // 64 x 32: two accumulators sharing every B fragment), two workgroups per CU -- half the operand bytes staged per MFMA, and
 // a k-step's 32 MFMAs per wave cover the latency of the next operand tile's loads even while the operands are still cold in
 // the XCD's L2 (all workgroups of a group walk k in step, so every k-step's first touch is a miss for all of them).
-template <int RB, int WPE>
+// GRAD: the data-parallel form of the same launch -- the tiles are STORED (P is then the gradient matrix; the ranks' gradients
+// have to meet before RMSprop may see them), the column sums are stored without their optimizer step, and there are no
+// RMSprop ranges.
+template <int RB, int WPE, bool GRAD = false>
 __global__ __launch_bounds__(NTHREADS, WPE) void gemm_f32_rms_persist_kernel(PersistArgs a) {
     constexpr int BMT = 64 * RB, NSUB = RB + 1, BUF_F = NSUB * TILE_F;       // A sub-tiles of 64 rows, then the B tile
     __shared__ __attribute__((aligned(16))) float lds[2 * BUF_F];
     const int b = blockIdx.x;
     if (b < a.small_blocks) {                                           // uniform over the workgroup
         int id = b;
-        if (id < a.m.cs_blocks) { colsum_multi_body256<true>(a.m.cs_desc, a.m.cs_nseg, a.m.cs, id, lds); return; }
+        if (id < a.m.cs_blocks) { colsum_multi_body256<!GRAD>(a.m.cs_desc, a.m.cs_nseg, a.m.cs, id, lds); return; }
         id -= a.m.cs_blocks;
-        if (id < a.m.rr_blocks) {
-            rmsprop_ranges_body(a.m.cs.pbase, a.m.cs.gbase, a.m.cs.sqbase, a.m.rr, a.m.cs.lr, a.m.cs.alpha, a.m.cs.eps,
-                                (long)id * NTHREADS + threadIdx.x);
-            return;
+        if constexpr (!GRAD) {
+            if (id < a.m.rr_blocks) {
+                rmsprop_ranges_body(a.m.cs.pbase, a.m.cs.gbase, a.m.cs.sqbase, a.m.rr, a.m.cs.lr, a.m.cs.alpha, a.m.cs.eps,
+                                    (long)id * NTHREADS + threadIdx.x);
+                return;
+            }
+            id -= a.m.rr_blocks;
         }
-        id -= a.m.rr_blocks;
         bn_running_layer_body(id / a.m.bn.bn_blocks ? a.m.bn.b : a.m.bn.a, (id % a.m.bn.bn_blocks) * NTHREADS + threadIdx.x,
                               a.m.bn.count, a.m.bn.momentum, a.m.bn.groups, a.m.bn.nupd_last);
         return;
@@ -598,6 +603,7 @@ __global__ __launch_bounds__(NTHREADS, WPE) void gemm_f32_rms_persist_kernel(Per
     // first row of accumulator block j of this wave, inside the tile
     auto row0 = [&](int j) { return RB == 2 ? wm * 64 + j * 32 : wm * 32; };
     auto prefetch_params = [&]() {
+        if constexpr (GRAD) return;
         // parameter / square-average tile: requested behind the LAST operand tile's loads (loads retire in order)
         const int pcol = min(n0 + wn * 32 + i, pm.N - 1);
 #pragma unroll
@@ -651,9 +657,13 @@ __global__ __launch_bounds__(NTHREADS, WPE) void gemm_f32_rms_persist_kernel(Per
                 for (int r = 0; r < 16; ++r) {
                     const int row = m0 + row0(j) + (r & 3) + 8 * (r >> 2) + 4 * h;
                     if (row < pm.M) {
-                        rmsprop_update(pp[j][r], sv[j][r], acc[j][r], a.m.g[0].lr, a.m.g[0].alpha, a.m.g[0].eps);
-                        pm.sq[(long)row * pm.ldp + col] = sv[j][r];
-                        pm.P[(long)row * pm.ldp + col] = pp[j][r];
+                        if constexpr (GRAD) {
+                            pm.P[(long)row * pm.ldp + col] = acc[j][r];
+                        } else {
+                            rmsprop_update(pp[j][r], sv[j][r], acc[j][r], a.m.g[0].lr, a.m.g[0].alpha, a.m.g[0].eps);
+                            pm.sq[(long)row * pm.ldp + col] = sv[j][r];
+                            pm.P[(long)row * pm.ldp + col] = pp[j][r];
+                        }
                     }
                 }
         }
@@ -1268,7 +1278,16 @@ int wfd_gemm_f32_rmsprop(int layout, const float* A, int lda, const float* B, in
 // then launches them one by one.
 static int rms_multi_launch(const long long* desc, int n, float lr, float alpha, float eps, const long long* cs_desc,
                             int cs_nseg, int cs_blocks, const ColsumOpt& cs, void* stream, const RmsRanges* rr = nullptr,
-                            int rr_blocks = 0, const BnRun* bn = nullptr);
+                            int rr_blocks = 0, const BnRun* bn = nullptr, bool grad = false);
+
+// The data-parallel form: the same products as ONE launch with their tiles STORED to the gradient matrices (desc words 7 / 8:
+// the gradient matrix and its row stride; word 9 unused), optionally carrying wfd_colsum_multi(cs_desc, cs_nseg, cs_blocks)
+// -- the step's column sums WITHOUT an optimizer step -- in its first workgroups.  WFD_ERR_ARG when the fast form does not
+// apply (fewer than 8 tiles, unaligned operands, N <= 32): the caller launches the products one by one.
+int wfd_gemm_f32_multi_grad(const long long* desc, int n, const long long* cs_desc, int cs_nseg, int cs_blocks, void* stream) {
+    if (cs_desc ? (cs_nseg <= 0 || cs_blocks <= 0) : (cs_nseg != 0 || cs_blocks != 0)) return WFD_ERR_ARG;
+    return rms_multi_launch(desc, n, 0.f, 0.f, 0.f, cs_desc, cs_nseg, cs_blocks, ColsumOpt{}, stream, nullptr, 0, nullptr, true);
+}
 
 int wfd_gemm_f32_rmsprop_multi(const long long* desc, int n, float lr, float alpha, float eps, void* stream) {
     return rms_multi_launch(desc, n, lr, alpha, eps, nullptr, 0, 0, ColsumOpt{}, stream);
@@ -1321,7 +1340,7 @@ int wfd_gemm_f32_rmsprop_multi_end(const long long* desc, int n, float lr, float
 
 static int rms_multi_launch(const long long* desc, int n, float lr, float alpha, float eps, const long long* cs_desc,
                             int cs_nseg, int cs_blocks, const ColsumOpt& cs, void* stream, const RmsRanges* rr, int rr_blocks,
-                            const BnRun* bn) {
+                            const BnRun* bn, bool grad) {
     // (runs the f32-operand kernel whatever wfd_set_gemm_mode says: weight gradients contract over the batch rows only
     // (K = 64 .. 512), where the bf16 pipe buys nothing, so every operand mode shares this launch)
     if (!desc || n < 1 || n > MULTI_MAX) return WFD_ERR_ARG;
@@ -1339,7 +1358,7 @@ static int rms_multi_launch(const long long* desc, int n, float lr, float alpha,
         float* P = reinterpret_cast<float*>(d[7]);
         float* SQ = reinterpret_cast<float*>(d[9]);
         const int lda = (int)d[1], ldb = (int)d[3], M = (int)d[4], N = (int)d[5], K = (int)d[6], ldp = (int)d[8];
-        if (!A || !B || !P || !SQ || M <= 0 || N <= 32 || K <= 0 || ldp < N || lda < M || ldb < N) return WFD_ERR_ARG;
+        if (!A || !B || !P || (!SQ && !grad) || M <= 0 || N <= 32 || K <= 0 || ldp < N || lda < M || ldb < N) return WFD_ERR_ARG;
         if (!aligned16(A) || !aligned16(B) || (lda & 3) || (ldb & 3) || !operands_fit(2, M, N, K, lda, ldb)) return WFD_ERR_ARG;
         GemmArgs& g = a.g[k];
         g.A = A; g.B = B; g.P = P; g.M = M; g.N = N; g.K = K; g.lda = lda; g.ldb = ldb; g.ldp = ldp;
@@ -1359,14 +1378,14 @@ static int rms_multi_launch(const long long* desc, int n, float lr, float alpha,
     static const int persist = getenv("WFD_RMS_PERSIST") ? atoi(getenv("WFD_RMS_PERSIST")) : 1;
     static const int rb_env = getenv("WFD_RMS_RB") ? atoi(getenv("WFD_RMS_RB")) : 1;
     static const int slots_env = getenv("WFD_RMS_SLOTS") ? atoi(getenv("WFD_RMS_SLOTS")) : 0;
-    if (persist && total >= 8) {
+    if ((persist || grad) && total >= 8) {
         PersistArgs pa{};
         pa.m = a;
         pa.small_blocks = small_blocks;
 #ifdef WFD_STAMPS
         pa.stamps = g_multi_stamps;
 #endif
-        const int rb = rb_env == 2 ? 2 : 1;
+        const int rb = (rb_env == 2 && !grad) ? 2 : 1;
         long worst = 0;
         for (int k = 0; k < n; ++k) {
             // split of problem k's gy x gx tile grid over the 8 XCD groups as pr x pc slabs: least tiles on the fullest
@@ -1396,11 +1415,13 @@ static int rms_multi_launch(const long long* desc, int n, float lr, float alpha,
         pa.nslots = nslots;
         const dim3 grid((unsigned)(small_blocks + 8 * nslots));
         hipStream_t st = (hipStream_t)stream;
-        if (rb == 2) hipLaunchKernelGGL((gemm_f32_rms_persist_kernel<2, 2>), grid, dim3(NTHREADS), 0, st, pa);
+        if (grad) hipLaunchKernelGGL((gemm_f32_rms_persist_kernel<1, 3, true>), grid, dim3(NTHREADS), 0, st, pa);
+        else if (rb == 2) hipLaunchKernelGGL((gemm_f32_rms_persist_kernel<2, 2>), grid, dim3(NTHREADS), 0, st, pa);
         else hipLaunchKernelGGL((gemm_f32_rms_persist_kernel<1, 3>), grid, dim3(NTHREADS), 0, st, pa);
         WFD_CHECK_LAUNCH();
         return WFD_OK;
     }
+    if (grad) return WFD_ERR_ARG;            // (the one-tile-per-workgroup form only exists with RMSprop in its store)
     hipLaunchKernelGGL(gemm_f32_rms_multi_kernel, dim3((unsigned)(total + small_blocks)), dim3(NTHREADS), 0, (hipStream_t)stream, a);
     WFD_CHECK_LAUNCH();
     return WFD_OK;

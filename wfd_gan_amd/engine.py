@@ -294,6 +294,13 @@ class TrainEngine:
         if self.mesh_dp and self.shard:
             raise ValueError("WFD_DP_MESH and WFD_DP_SHARD are two forms of the same step: choose one")
         self._mesh = None
+        # "late gradients": the data-parallel step keeps the single-GPU shape (whole chain first, then all weight gradients
+        # and column sums as ONE launch, then one exchange of the whole buffer) instead of interleaving weight gradients with
+        # the chain so that buckets can leave early.  Default with the mesh form (its exchange is in-stream, nothing can leave
+        # early: +5 % at world 1); WFD_DP_LATE_GRADS=1 selects it for the all-reduce form too (one collective instead of
+        # three, no early buckets), =0 switches it off everywhere.
+        lg = os.environ.get("WFD_DP_LATE_GRADS", "")
+        self.late_grads = self.dp and not self.shard and not overlap and (lg == "1" or (self.mesh_dp and lg != "0"))
         self._comm = None
         self.nbt = {"model.3": 0, "model.6": 0}
         dev = self.dev
@@ -588,7 +595,11 @@ class TrainEngine:
             (b["DL1"][M:], 2048, None, None, 0, None, M, 2048, D.g["model.0.bias"]),
             (b["DL2"][M:], 1024, None, None, 0, None, M, 1024, D.g["model.3.bias"]),
             (b["DL3"][M:], 512, None, None, 0, None, M, 512, D.g["model.6.bias"])]
-        if self.dp:
+        # data parallel over the peer-to-peer exchange: nothing leaves before the end of the step, so the step keeps the
+        # single-GPU shape -- the whole t-chain first, then ALL weight gradients and column sums as one launch (stored, not
+        # consumed), then the one launch that sums the ranks' gradients, applies RMSprop and redistributes the parameters
+        late = self.late_grads
+        if self.dp and not late:
             # data parallel: the bias gradients (column sums of dv o delta_i, final once the chain is) are produced here,
             # ahead of the weight gradients, so that [W1, b1] and [W2, b2] can go out as whole buckets early
             self._colsum_multi(p, "d_bias", bias_segs)
@@ -601,7 +612,7 @@ class TrainEngine:
         # operands exist
         Dp = D.p
         d_problems = None
-        if self.fuse_d:
+        if self.fuse_d or late:
             # single GPU: the whole t-chain first (it reads W_1..W_3), then the three weight gradients, each consumed by RMSprop
             # in its own store, as ONE launch
             ld1 = D.ld["model.0.weight"]
@@ -612,7 +623,11 @@ class TrainEngine:
                 (b["DL1"], 2048, b["XC"], self.ldx, 2048, S + C, 2 * M, Dp["model.0.weight"], ld1, D.s["model.0.weight"]),
                 (b["DL2"], 1024, b["T1H1"], 2048, 1024, 2048, 2 * M, Dp["model.3.weight"], 2048, D.s["model.3.weight"]),
                 (b["DL3"], 512, b["T2H2"], 1024, 512, 1024, 2 * M, Dp["model.6.weight"], 1024, D.s["model.6.weight"])]
-            if os.environ.get("WFD_D_END_MERGE", "1") == "0":             # (the switch: same-session A/B)
+            if late:
+                # (stored to the gradient matrices instead: same operands, the gradient matrix in place of the parameter matrix)
+                d_problems = [pr[:7] + (D.g[n], D.ld[n]) for pr, n in zip(d_problems, ("model.0.weight", "model.3.weight",
+                                                                                       "model.6.weight"))]
+            elif os.environ.get("WFD_D_END_MERGE", "1") == "0":             # (the switch: same-session A/B)
                 p.gemm_rms_multi(d_problems, self.lr)
                 d_problems = None
         elif self.pair:
@@ -644,6 +659,13 @@ class TrainEngine:
             (b["V"], 1, b["NDV"], None, 0, None, M, 1, b["dstats"][2:3], b["dacc"][1:2]),
             (b["V"], 1, b["RSELR"], None, 0, None, M, 1, b["dstats"][3:4]),
             (b["V"], 1, b["RSELF"], None, 0, None, M, 1, b["dstats"][4:5])]
+        if late:
+            desc, blk = self._colsum_desc(p, d_segs)
+            if not p.gemm_multi_grad(d_problems, colsum=(ptr(desc), len(d_segs), blk)):
+                self._colsum_multi(p, "d_small", d_segs, opt=None)
+            self._grad_sync_hook(p, "D", st_arg)
+            self._optimizer(p, D, False, *st_arg)
+            return p
         if self.fuse_d and d_problems is not None:
             # ... and those column sums ride in the first workgroups of the weight-gradient launch: the end of the D-step
             # is ONE launch (they read the chain's activations and row scalars, never the parameter matrices)
@@ -763,7 +785,7 @@ class TrainEngine:
                 st = tuple(st_arg) if st_arg is not None else (0, 0, 0)
                 p.host(lambda: (gs.start(fp.flat, fp.grad, fp.sq, lo, hi, lr, gscale, st), gs.finish()), gs.capturable)
             return
-        bucket = fp.grad[lo:hi]
+        bucket = fp.grad if self.late_grads else fp.grad[lo:hi]       # late gradients: ONE collective over the whole buffer
         if stage < 2:
             p.host(lambda: gs.start(bucket), gs.capturable)
         else:
@@ -982,6 +1004,28 @@ class TrainEngine:
                           self.lr, 0.99, 1e-8, *st_arg, *bn_run)
             else:
                 self._optimizer(p, G, True, st if fast else 0, self._rng_inc() if fast else 0, 0)
+            return p
+        if self.late_grads:
+            # data parallel over the peer-to-peer exchange: the single-GPU shape -- the activation-gradient chain, then all four
+            # weight gradients as one launch (stored), then the exchange launch
+            s = p.gemm(NN, b["GDZ4"], self.lds4, Gp["model.8.weight"], 2048, B, 2048, S)
+            self._bn_bwd(p, s, 3, "model.5", "model.6", 2048)
+            s = p.gemm(NN, b["GDZ3"], 2048, Gp["model.5.weight"], 1024, B, 1024, 2048)
+            self._bn_bwd(p, s, 2, "model.2", "model.3", 1024)
+            p.gemm_mul(NN, b["GDZ2"], 1024, Gp["model.2.weight"], 512, B, 512, 1024, b["GH1"], 512, DM_RELU, None, b["GDZ1"], 512)
+            desc = torch.tensor([[ptr(b["GDZ1"]), 512, 0, 0, 0, 0, B, 512, ptr(G.g["model.0.bias"]), 0, 0]],
+                                dtype=torch.int64, device=self.dev)
+            p.keep.append(desc)
+            if not p.gemm_multi_grad([
+                    (b["GDZ4"], self.lds4, b["GH3"], 2048, S, 2048, B, G.g["model.8.weight"], 2048),
+                    (b["GDZ3"], 2048, b["GH2"], 1024, 2048, 1024, B, G.g["model.5.weight"], 1024),
+                    (b["GDZ2"], 1024, b["GH1"], 512, 1024, 512, B, G.g["model.2.weight"], 512),
+                    (b["GDZ1"], 512, b["ZIN"], self.ldz, 512, Z + C, B, G.g["model.0.weight"], G.ld["model.0.weight"])],
+                    colsum=(ptr(desc), 1, 512 // 32)):
+                p.add(self.L.colsum, ptr(b["GDZ1"]), 512, B, 512, 0, ptr(G.g["model.0.bias"]), 0)
+            g_st = (st if fast else 0, self._rng_inc() if fast else 0, 0)
+            self._grad_sync_hook(p, "G", g_st)
+            self._optimizer(p, G, False, *g_st)
             return p
         s = p.gemm_pair((b["GDZ4"], self.lds4, b["GH3"], 2048, S, 2048, B, G.g["model.8.weight"], 2048),
                         (NN, b["GDZ4"], self.lds4, Gp["model.8.weight"], 2048, B, 2048, S), pair=pr)

@@ -329,6 +329,29 @@ class Plan:
             self.add(self.L.gemm_f32_rmsprop_multi, arr, len(chunk), lr, alpha, eps)
         return False
 
+    def gemm_multi_grad(self, problems, colsum=None) -> bool:
+        """Several independent weight gradients STORED by ONE launch (wfd_gemm_f32_multi_grad; the data-parallel form, whose
+        gradients have to meet the other ranks' before the optimizer sees them); problems: [(A, lda, B, ldb, M, N, K, G, ldg)]
+        of TN products, at most 4.  colsum = (desc_ptr, nseg, blocks): the launch also carries that wfd_colsum_multi.  Returns
+        True when it did; where the fast form does not apply the products go out one by one and the caller launches the
+        column sums."""
+        import ctypes
+        ok = all(N > 32 and ptr(A) % 16 == 0 and ptr(B) % 16 == 0 and lda % 4 == 0 and ldb % 4 == 0
+                 for A, lda, B, ldb, M, N, K, G, ldg in problems)
+        tiles = sum(-(-M // 64) * -(-N // 64) for A, lda, B, ldb, M, N, K, G, ldg in problems)
+        if not ok or not 2 <= len(problems) <= 4 or tiles < 8 or os.environ.get("WFD_RMS_MULTI", "1") == "0":
+            for A, lda, B, ldb, M, N, K, G, ldg in problems:
+                self.gemm(TN, A, lda, B, ldb, M, N, K, out=G, ldp=ldg)
+            return False
+        words = []
+        for A, lda, B, ldb, M, N, K, G, ldg in problems:
+            words += [ptr(A), lda, ptr(B), ldb, M, N, K, ptr(G), ldg, 0]
+        arr = (ctypes.c_longlong * len(words))(*words)
+        self.keep.append(arr)
+        cs = colsum if colsum is not None else (0, 0, 0)
+        self.add(self.L.gemm_f32_multi_grad, arr, len(problems), *cs)
+        return colsum is not None
+
     def gemm_pair(self, tn, other, pair: bool = True) -> Slabs:
         """A weight gradient and the next product of the backward chain, which do not depend on each other, as ONE launch
         (wfd_gemm_f32_pair): tn = (A, lda, B, ldb, M, N, K, out, ldp) is the TN product written straight to ``out``;
