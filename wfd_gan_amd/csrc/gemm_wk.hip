@@ -511,7 +511,9 @@ int wfd_gemm_wk_pick(int layout, int M, int N, int K) {
     // 129 .. 256 rows (the stacked generator forwards of a group: 192; the critic under --penalty gp: 192): with 32-row tiles
     // the tile count lands just above a multiple of the 256 CUs (192 x 1401: 264 tiles, 192 x 2048: 384) and the launch runs
     // two rounds of workgroups; 48-row tiles (cfg 6) make it one round of 1.5x the work each
-    if (layout == 0 && M > 128 && nchunk >= 16) {
+    // (NN too: under --penalty gp the critic's chain products have 192 rows as well; in-step tuner, profiles/r03_wk_tune_gp.json:
+    // 192 x 1401 x 2048 -2.4 %, 192 x 2048 x 1024 -1.0 % per group)
+    if ((layout == 0 || layout == 1) && M > 128 && nchunk >= 16) {
         const long t48 = (long)cdiv(M, 48) * cdiv(N, 32);
         static const int use48 = getenv("WFD_WK_48") ? atoi(getenv("WFD_WK_48")) : 1;       // (the switch: same-session A/B)
         if (use48 && cdiv(t48, 256) * 48 < cdiv(t32, 256) * 32) return 6;
