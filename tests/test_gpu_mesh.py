@@ -47,7 +47,7 @@ def run_ranks(world, script, tmp_path, extra_env=None, timeout=240):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("world", [1, 2, 3, 4])
+@pytest.mark.parametrize("world", [1, 2, 3, 4, 6, 8])
 def test_mesh_exchange_between_processes(world, tmp_path):
     for r in run_ranks(world, "mesh_worker.py", tmp_path):
         assert r["ok"] and r["timeouts"] == 0, r
