@@ -613,6 +613,8 @@ def main():
             torch.cuda.empty_cache()
         if args.operands == "f32" and args.batch == 64 and args.seq_len == 1401 and args.classes == 100 and args.inst == 1000:
             extras["cli_epoch"] = cli_epoch(device)
+    if eng._mesh is not None:
+        eng._mesh.check()                 # a timed-out wait for a peer would make the line meaningless: fail before printing it
     if rank == 0:
         out = {
             "metric": "WGAN train iterations/s (100-class, L=1400, fp32; one iteration = loop body on one 64-row batch: "

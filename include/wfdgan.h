@@ -496,8 +496,11 @@ int wfd_argmax_correct(const float* logits, int ldl, int M, int C, const int* la
  * maps theirs with wfd_mesh_open and builds a mesh from the W region / flag pointers in rank order (its own entries are
  * its own allocations).  After that an exchange is ONE kernel launch on the caller's stream (capturable in a HIP graph):
  * start barrier -> every rank sums its 1/W shard from all ranks in rank order and stores the result to all ranks -> end
- * barrier (wfd_gan_amd/csrc/mesh.hip).  All ranks must issue the same sequence of exchanges.  Waits are bounded (2 s): a
- * peer that never arrives is counted in wfd_mesh_status' third word instead of hanging the GPU.
+ * barrier (wfd_gan_amd/csrc/mesh.hip).  All ranks must issue the same sequence of exchanges, one at a time per mesh.  Waits
+ * are bounded (20 s by default, wfd_mesh_set_timeout_ms): a peer that never arrives is counted in wfd_mesh_status' third word
+ * instead of hanging the GPU -- the exchange's result is then undefined, so check the status at a point where the host
+ * synchronises anyway (the Python layer does at every epoch end), and keep ranks from running far ahead of a rank that is
+ * busy on the host (a host barrier after rank-0-only work).
  * kind 0: region (hipMalloc), 1: flag block (wfd_mesh_flag_bytes() bytes, uncached); both zeroed; handle: 64 bytes out. */
 int wfd_mesh_flag_bytes(void);
 int wfd_mesh_alloc(long bytes, int kind, void** ptr, void* ipc_handle);
@@ -511,6 +514,8 @@ int wfd_mesh_destroy(void* mesh);
 /* workgroups (1024 threads) an exchange may use, 1 .. 256 (default 128, one per second CU).  Every workgroup of every rank waits
  * for the peers, so all of them must be resident at once: ranks that SHARE a GPU (test rigs) must split its CUs. */
 int wfd_mesh_set_max_blocks(void* mesh, int max_blocks);
+/* bound of every in-kernel wait for a peer, 1 ms .. 10 min (default 20 s) */
+int wfd_mesh_set_timeout_ms(void* mesh, long ms);
 /* region[off, off + n) <- sum over ranks, in place on every rank, identical bits everywhere (off, n multiples of 4) */
 int wfd_mesh_allreduce_f32(void* mesh, long off, long n, void* stream);
 /* the data-parallel optimizer step as ONE launch: g = gscale * sum over ranks of region[grad_off + i] (rank order), RMSprop

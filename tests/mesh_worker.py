@@ -145,6 +145,40 @@ def main():
     done, timeouts = mesh.status()
     res["exchanges"], res["timeouts"] = done, timeouts
     ok &= timeouts == 0 and done == len(sizes) + n_small + 1 + 3 and ok_share
+    # ---- a peer that stays away longer than the bound: counted, never a hang; the exchange numbering survives it
+    if world == 2:
+        import time
+        L.mesh_set_timeout_ms(mesh.mesh, 300)
+        dist.barrier()
+        v = mesh.alloc_small(64)
+        v.fill_(float(rank + 1))
+        torch.cuda.synchronize()
+        dist.barrier()
+        if rank == 1:
+            time.sleep(1.5)                           # rank 0 is inside the kernel, waiting for START[1], for 0.3 s only
+        t0 = time.time()
+        L.mesh_allreduce_small(mesh.mesh, mesh.offset_of(v), 64, st)
+        torch.cuda.synchronize()
+        took = time.time() - t0
+        _, t_after = mesh.status()
+        res["late_peer"] = dict(took=round(took, 2), timeouts=t_after)
+        ok &= took < 5.0 and ((t_after > 0) if rank == 0 else True)
+        try:
+            mesh.check()
+            raised = False
+        except RuntimeError:
+            raised = True
+        ok &= raised == (t_after > 0)
+        dist.barrier()
+        L.mesh_set_timeout_ms(mesh.mesh, 20000)
+        v.fill_(float(rank + 1))
+        torch.cuda.synchronize()
+        dist.barrier()
+        L.mesh_allreduce_small(mesh.mesh, mesh.offset_of(v), 64, st)
+        torch.cuda.synchronize()
+        _, t_again = mesh.status()
+        res["after_late_peer"] = dict(value=float(v[0].item()), new_timeouts=t_again - t_after)
+        ok &= t_again == t_after and float(v[0].item()) == 3.0 and float(v[63].item()) == 3.0
     res["ok"] = bool(ok)
     del gr, grad, par
     parallel.shutdown()

@@ -23,8 +23,8 @@
 //                       next launch on the stream sees every peer's pushes, and no peer still reads this rank's region.
 //
 // Flags are monotonically increasing collective numbers (no reset, no ABA), one per 128-byte line, in an uncached
-// allocation of their own; all flag traffic uses system-scope release stores / acquire loads.  Every wait is BOUNDED (2 s
-// of the 100 MHz wall clock): a peer that never arrives is counted in the error word and the kernel ends -- no wave can
+// allocation of their own; all flag traffic uses system-scope release stores / acquire loads.  Every wait is BOUNDED (20 s
+// of the 100 MHz wall clock by default, wfd_mesh_set_timeout_ms): a peer that never arrives is counted in the error word and the kernel ends -- no wave can
 // spin for ever.  The collective number lives in device memory (not in a kernel argument), so a captured graph replays it.
 #include "common.h"
 #include <cstring>
@@ -34,7 +34,7 @@ namespace {
 constexpr int MAXW = 8;
 constexpr int FLAG_WORDS = 32;                                   // one flag per 128-byte line
 constexpr long FLAG_BLOCK_BYTES = 2L * MAXW * FLAG_WORDS * 4;    // START[8] then DONE[8]
-constexpr unsigned long long SPIN_TICKS = 200000000ull;          // 2 s at 100 MHz
+constexpr unsigned long long DEFAULT_SPIN_TICKS = 2000000000ull;  // 20 s at 100 MHz (wfd_mesh_set_timeout_ms)
 constexpr int MESH_THREADS = 1024;                               // large workgroups: the fences are per workgroup
 constexpr int MESH_MAX_BLOCKS = 256;                             // one per CU: all resident at once (they wait for peers);
                                                                  // wfd_mesh_set_max_blocks lowers it for ranks sharing a GPU
@@ -43,6 +43,7 @@ struct MeshDev {                 // by-value kernel argument
     float* data[MAXW];           // rank p's exchange region as mapped into THIS process
     unsigned* flags[MAXW];       // rank p's flag block as mapped into this process
     unsigned* local;             // this rank's private words: [0] collectives completed, [1] workgroup ticket, [2] time-outs
+    unsigned long long spin_ticks;   // bound of every wait, in ticks of the 100 MHz wall clock
     int rank, world;
 };
 
@@ -62,11 +63,11 @@ __device__ __forceinline__ unsigned ld_sys(const unsigned* p) {
     return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 
-// until *f has reached collective number e (wrap-safe), at most SPIN_TICKS
-__device__ __forceinline__ bool wait_flag(const unsigned* f, unsigned e) {
+// until *f has reached collective number e (wrap-safe), at most `limit` ticks
+__device__ __forceinline__ bool wait_flag(const unsigned* f, unsigned e, unsigned long long limit) {
     const unsigned long long t0 = wall_clock64();
     while ((int)(ld_sys(f) - e) < 0) {
-        if (wall_clock64() - t0 > SPIN_TICKS) return false;
+        if (wall_clock64() - t0 > limit) return false;
         __builtin_amdgcn_s_sleep(4);
     }
     return true;
@@ -88,7 +89,7 @@ __global__ __launch_bounds__(MESH_THREADS) void mesh_exchange_kernel(MeshDev m, 
     }
     // (A)
     if (blockIdx.x == 0 && tid < W) st_sys(m.flags[tid] + r * FLAG_WORDS, e);
-    if (tid < W) ok = wait_flag(m.flags[r] + tid * FLAG_WORDS, e);
+    if (tid < W) ok = wait_flag(m.flags[r] + tid * FLAG_WORDS, e, m.spin_ticks);
     // ONE wave per workgroup acquires at system scope (a cache invalidate; the waves of a workgroup share the CU's caches and
     // the barrier orders the others behind it): a fence per wave made this phase, not the data, the cost of the launch
     if (tid < 64) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "");
@@ -153,7 +154,7 @@ __global__ __launch_bounds__(MESH_THREADS) void mesh_exchange_kernel(MeshDev m, 
         }
     }
     if (tid < W) {
-        ok = wait_flag(m.flags[r] + (MAXW + tid) * FLAG_WORDS, e) && ok;
+        ok = wait_flag(m.flags[r] + (MAXW + tid) * FLAG_WORDS, e, m.spin_ticks) && ok;
         if (!ok) __hip_atomic_fetch_add(m.local + 2, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
     // (the launch ends here: the next launch on the stream starts with its own acquire and then sees every peer's stores)
@@ -174,7 +175,7 @@ __global__ __launch_bounds__(MESH_THREADS) void mesh_small_kernel(MeshDev m, lon
     const unsigned e = __hip_atomic_load(m.local, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1u;
     bool ok = true;
     if (blockIdx.x == 0 && tid < W) st_sys(m.flags[tid] + r * FLAG_WORDS, e);
-    if (tid < W) ok = wait_flag(m.flags[r] + tid * FLAG_WORDS, e);
+    if (tid < W) ok = wait_flag(m.flags[r] + tid * FLAG_WORDS, e, m.spin_ticks);
     if (tid < 64) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "");
     __syncthreads();
     const int j = blockIdx.x * MESH_THREADS + tid;
@@ -214,7 +215,7 @@ __global__ __launch_bounds__(MESH_THREADS) void mesh_small_kernel(MeshDev m, lon
         }
     }
     if (tid < W) {
-        ok = wait_flag(m.flags[r] + (MAXW + tid) * FLAG_WORDS, e) && ok;
+        ok = wait_flag(m.flags[r] + (MAXW + tid) * FLAG_WORDS, e, m.spin_ticks) && ok;
         if (!ok) __hip_atomic_fetch_add(m.local + 2, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
     __syncthreads();                              // every rank has read this rank's source: now it may be overwritten
@@ -338,6 +339,7 @@ int wfd_mesh_create(int rank, int world, void* const* data, void* const* flags, 
     }
     ms->d.rank = rank;
     ms->d.world = world;
+    ms->d.spin_ticks = DEFAULT_SPIN_TICKS;
     ms->region_floats = region_floats;
     ms->max_blocks = MESH_MAX_BLOCKS / 2;       // measured at world 1: 64 / 128 / 256 workgroups -> 2892 / 2924 / 2849 it/s
     if (hipGetDevice(&ms->device) != hipSuccess || hipMalloc((void**)&ms->d.local, 256) != hipSuccess ||
@@ -353,6 +355,12 @@ int wfd_mesh_create(int rank, int world, void* const* data, void* const* flags, 
 int wfd_mesh_set_max_blocks(void* mesh, int max_blocks) {
     if (!mesh || max_blocks < 1 || max_blocks > MESH_MAX_BLOCKS) return WFD_ERR_ARG;
     static_cast<Mesh*>(mesh)->max_blocks = max_blocks;
+    return WFD_OK;
+}
+
+int wfd_mesh_set_timeout_ms(void* mesh, long ms) {
+    if (!mesh || ms < 1 || ms > 600000) return WFD_ERR_ARG;
+    static_cast<Mesh*>(mesh)->d.spin_ticks = (unsigned long long)ms * 100000ull;
     return WFD_OK;
 }
 

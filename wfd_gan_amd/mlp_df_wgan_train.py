@@ -272,6 +272,8 @@ def main(argv=None):
         eng.reshuffle()
         eng.check_length_index()
         dacc, gacc = eng.epoch_sums()                     # the epoch's only host sync (and loss collective)
+        if eng._mesh is not None:
+            eng._mesh.check()                             # peer-to-peer exchange: no wait for a peer may have timed out
         d_ep, w_ep = dacc[0] / n_batches, dacc[1] / n_batches
         div_g = max(n_batches // args.n_critic, 1)
         g_ep, f_ep, comb_ep = gacc[0] / div_g, gacc[1] / div_g, gacc[2] / div_g
@@ -290,6 +292,8 @@ def main(argv=None):
                 total_real, total_fake = epoch_dump(scaler, X[sel], fake_all)            # float64 / float32, as :291-292
                 np.savez_compressed(join(checkpointdir, "epoch_{}".format(epoch + 1)), x=total_real,
                                     recon_x=total_fake, label=y[sel])
+            if eng._mesh is not None:
+                eng._mesh.wait_for_peers()                # nobody waits for rank 0's file INSIDE the next exchange kernel
         losses["generator"].append(g_ep)
         losses["discriminator"].append(d_ep)
         losses["dist"].append(w_ep)

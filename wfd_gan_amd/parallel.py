@@ -342,6 +342,9 @@ class MeshSync:
             sharing = self._ranks_on_my_gpu()
             blocks = int(os.environ.get("WFD_MESH_BLOCKS", "0")) or 128 // sharing
             lib.mesh_set_max_blocks(self.mesh, max(1, min(256, blocks)))
+            # bound of every in-kernel wait for a peer (a rank busy on the host -- rank 0 writing a checkpoint -- keeps the
+            # others waiting inside their next exchange; callers put a host barrier behind such work, see wait_for_peers)
+            lib.mesh_set_timeout_ms(self.mesh, int(1000 * float(os.environ.get("WFD_MESH_TIMEOUT_S", "20"))))
             self.sharing = sharing
         if self.base.data_ptr() != self.region.ptr or self.base.numel() != n:
             raise RuntimeError("exchange region: torch did not wrap the allocation in place")
@@ -391,6 +394,20 @@ class MeshSync:
         out = (ctypes.c_long * 3)()
         self.L.mesh_status(self.mesh, out)
         return int(out[0]), int(out[2])
+
+    def check(self):
+        """Raise if a wait for a peer ever timed out (the result of that exchange is undefined).  Synchronises the device:
+        call it where the host synchronises anyway (epoch ends)."""
+        done, timeouts = self.status()
+        if timeouts:
+            raise RuntimeError(f"mesh exchange: {timeouts} waits for a peer timed out ({done} exchanges issued on rank "
+                               f"{self.rank}); a rank died or stayed away longer than WFD_MESH_TIMEOUT_S")
+
+    def wait_for_peers(self):
+        """Host barrier: call after work that only some ranks do (rank 0 writing files), so that no rank waits for it INSIDE
+        an exchange kernel (whose waits are bounded)."""
+        if self.active and self.world > 1:
+            dist.barrier(self.group)
 
     def close(self):
         """Collective: every rank unmaps its peers' regions, then drops its own mesh.  The region itself is freed when the
