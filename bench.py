@@ -105,7 +105,9 @@ def gemm_roofline(eng, plans=None, rep=16, rounds=3):
                 L.conv8_gemm_f32_fused: "conv", L.conv8_gemm_f32_fused_pool: "conv", L.gemm_f32_pair: "pair", L.gemm_f32_wk: "gemm_wk", L.conv8_f32_wk: "conv",
                 L.gemm_f32_rmsprop: "gemm_rms", L.gemm_f32_rmsprop_multi: "rms_multi", L.gemm_f32_wk_multi: "wk_multi",
                 # (the same launch also carrying the step's column sums / small updates in a few extra workgroups)
-                L.gemm_f32_rmsprop_multi_colsum: "rms_multi", L.gemm_f32_rmsprop_multi_end: "rms_multi"}
+                L.gemm_f32_rmsprop_multi_colsum: "rms_multi", L.gemm_f32_rmsprop_multi_end: "rms_multi",
+                # (data parallel, late gradients: the same products, stored instead of consumed)
+                L.gemm_f32_multi_grad: "rms_multi"}
     calls = []
     for plan, weight in (plans or ((eng.fast_d, eng.n_critic), (eng.fast_g, 1))):
         for fn, a, _lane in plan.calls:
