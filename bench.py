@@ -90,6 +90,48 @@ def run_steps(eng, start, n):
             i += 1
 
 
+def live_traffic(timeout_s: float = 150.0):
+    """HBM bytes per launch of the contraction core, MEASURED for this run: two `rocprofv3 --pmc` passes (FETCH_SIZE, then
+    WRITE_SIZE: separate runs, as MI355X_MICROARCH's HBM section prescribes; --kernel-trace only beside them) of this
+    script's short un-graphed form as CHILD processes (python3 directly behind `--`), summarised by tools/pmc_traffic.py
+    with the guide's unit and gfx950 corrections (KiB; FETCH x 2).  None when rocprofv3 is missing or a pass fails or times
+    out -- the caller then falls back to the committed passes and says so."""
+    import importlib.util
+    import shutil
+    import signal
+    import subprocess
+    import tempfile
+    rocprof = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
+    if not os.path.exists(rocprof):
+        return None
+    tmp = tempfile.mkdtemp(prefix="wfd_pmc_", dir="/tmp")
+    child = [sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "12", "--warmup", "3", "--repeats", "1", "--no-graph",
+             "--no-cpu-baseline", "--no-sampling", "--no-modes", "--no-extras"]
+    env = dict(os.environ, TMPDIR="/tmp")
+    try:
+        for counter in ("FETCH_SIZE", "WRITE_SIZE"):
+            cmd = [rocprof, "--pmc", counter, "--kernel-trace", "--output-format", "csv", "-d", os.path.join(tmp, counter), "--"] + child
+            p = subprocess.Popen(cmd, cwd="/tmp", env=env, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL,
+                                 start_new_session=True)
+            try:
+                rc = p.wait(timeout=timeout_s)
+            except subprocess.TimeoutExpired:
+                os.killpg(p.pid, signal.SIGKILL)          # the process group this function started, nothing else
+                p.wait()
+                return None
+            if rc != 0:
+                return None
+        spec = importlib.util.spec_from_file_location("pmc_traffic", os.path.join(ROOT, "tools", "pmc_traffic.py"))
+        mod = importlib.util.module_from_spec(spec)
+        spec.loader.exec_module(mod)
+        res = mod.summarise(os.path.join(tmp, "FETCH_SIZE"), os.path.join(tmp, "WRITE_SIZE"), "live")
+        return res if res["_gemm_all"]["launches"] > 0 else None
+    except Exception:
+        return None
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
+
+
 def gemm_roofline(eng, plans=None, rep=16, rounds=3):
     """Live timing of the dominant kernel (the fp32 MFMA GEMM core, all its layouts) at the launches of one group of
     three iterations (3 D-steps + 1 G-step).  Every GEMM launch of the fast-mode plans is captured `rep` times
@@ -369,6 +411,8 @@ def main():
     ap.add_argument("--no-modes", action="store_true", help="skip the bf16x3 / bf16 operand-mode runs of the same step")
     ap.add_argument("--no-extras", action="store_true",
                     help="skip the short WGAN-GP (--penalty gp) block, the trainer-CLI epoch and the per-launch time sum")
+    ap.add_argument("--no-live-traffic", action="store_true",
+                    help="roofline.traffic from the committed PMC passes instead of two rocprofv3 --pmc passes of this run")
     ap.add_argument("--cpu-seconds", type=float, default=20.0)
     args = ap.parse_args()
 
@@ -454,13 +498,22 @@ def main():
 
     # the launches of the plans that were timed above (one group of n_critic iterations either way)
     roof = gemm_roofline(eng, [(drv.group, 1)] if grouped else None)
-    traffic, traffic_commit = None, None      # HBM bytes per contraction launch from the committed PMC passes (tools/pmc_traffic.py)
-    try:
-        pm = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))
-        traffic = pm["_gemm_all"]["hbm_bytes_per_launch"]
-        traffic_commit = pm.get("_meta", {}).get("commit")
-    except Exception:
-        pass
+    # HBM bytes per contraction launch: measured for THIS run by two PMC passes of the un-graphed step in child processes
+    # (headline configuration, one rank); otherwise -- and when a pass fails -- the committed passes (tools/pmc_traffic.py)
+    traffic, traffic_commit, traffic_live = None, None, None
+    headline = (world == 1 and grouped and args.operands == "f32" and args.batch == 64 and args.seq_len == 1401
+                and args.classes == 100 and args.penalty == "div" and not args.no_graph)
+    if headline and not args.no_extras and not args.no_live_traffic:
+        traffic_live = live_traffic()
+    if traffic_live is not None:
+        traffic = traffic_live["_gemm_all"]["hbm_bytes_per_launch"]
+    else:
+        try:
+            pm = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))
+            traffic = pm["_gemm_all"]["hbm_bytes_per_launch"]
+            traffic_commit = pm.get("_meta", {}).get("commit")
+        except Exception:
+            pass
     samp = None
     if not args.no_sampling:
         from wfd_gan_amd.sampler import BulkSampler
@@ -646,9 +699,16 @@ def main():
                        "optimizer_in_gradient_store": {"critic": bool(eng.fuse_d), "generator": bool(eng.fuse_g)}},
             "roofline": {"bound": "mfma", "achieved": roof["tflops"], "peak": peak, "unit": "TFLOP/s",
                          "frac": roof["tflops"] / peak, "traffic": traffic if args.operands == "f32" else None,
-                         "traffic_note": "bytes/launch, NOT measured in this run: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of "
-                                         "this command (--no-graph --steps 12) committed as profiles/pmc_traffic.json, taken at "
-                                         f"commit {traffic_commit}; FETCH x2 per MI355X_MICROARCH HBM section",
+                         "traffic_note": ("bytes/launch, MEASURED IN THIS RUN: rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE passes "
+                                          "(separate child processes) of this command's un-graphed form (--no-graph --steps 12), "
+                                          "FETCH x2 per MI355X_MICROARCH HBM section; average over the contraction launches"
+                                          if traffic_live is not None else
+                                          "bytes/launch, NOT measured in this run: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of "
+                                          "this command (--no-graph --steps 12) committed as profiles/pmc_traffic.json, taken at "
+                                          f"commit {traffic_commit}; FETCH x2 per MI355X_MICROARCH HBM section"),
+                         "traffic_by_kernel": ({k: round(v["hbm_bytes_per_launch"]) for k, v in traffic_live.items()
+                                                if not k.startswith("_") and (k.startswith("gemm") or k.startswith("conv8_c32"))}
+                                               if traffic_live is not None else None),
                          "kernel": core, "launches_timed": roof["launches"],
                          "avg_flops_per_launch": roof["avg_flops"], "avg_us_per_launch": roof["avg_us"]},
         }
