@@ -155,7 +155,7 @@ def main():
         torch.cuda.synchronize()
         dist.barrier()
         if rank == 1:
-            time.sleep(1.5)                           # rank 0 is inside the kernel, waiting for START[1], for 0.3 s only
+            time.sleep(3.0)                           # rank 0 is inside the kernel, waiting for START[1], for 0.3 s only
         t0 = time.time()
         L.mesh_allreduce_small(mesh.mesh, mesh.offset_of(v), 64, st)
         torch.cuda.synchronize()
