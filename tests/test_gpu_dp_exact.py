@@ -42,7 +42,7 @@ def test_exact_dp_equals_reference_update(name, world, mesh, monkeypatch):
 
 
 @pytest.mark.parametrize("name,world,shard", [("cfg1", 2, False), ("cfg2", 3, False), ("cfg1", 2, True), ("cfg2", 3, True),
-                                              ("cfg1", 2, "mesh"), ("cfg2", 3, "mesh")])
+                                              ("cfg1", 2, "mesh"), ("cfg2", 3, "mesh"), ("cfg1", 8, "mesh")])
 def test_weak_dp_buckets_sum_every_gradient(name, world, shard, monkeypatch):
     """Weak mode (per-rank batches): with the bucketed asynchronous all-reduce the flat gradient buffers hold the sum of the
     ranks' local gradients everywhere; with the sharded optimizer (WFD_DP_SHARD=1) every rank's shards hold it and the
