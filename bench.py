@@ -90,7 +90,7 @@ def run_steps(eng, start, n):
             i += 1
 
 
-def live_traffic(timeout_s: float = 150.0):
+def live_traffic(timeout_s: float = 90.0):
     """HBM bytes per launch of the contraction core, MEASURED for this run: two `rocprofv3 --pmc` passes (FETCH_SIZE, then
     WRITE_SIZE: separate runs, as MI355X_MICROARCH's HBM section prescribes; --kernel-trace only beside them) of this
     script's short un-graphed form as CHILD processes (python3 directly behind `--`), summarised by tools/pmc_traffic.py
@@ -103,6 +103,9 @@ def live_traffic(timeout_s: float = 150.0):
     import tempfile
     rocprof = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
     if not os.path.exists(rocprof):
+        return None
+    # already under a profiler (someone runs `rocprofv3 ... -- python3 bench.py`): no nested passes
+    if any(k.startswith(("ROCPROF", "ROCP_")) for k in os.environ) or "rocprof" in os.environ.get("LD_PRELOAD", ""):
         return None
     tmp = tempfile.mkdtemp(prefix="wfd_pmc_", dir="/tmp")
     child = [sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "12", "--warmup", "3", "--repeats", "1", "--no-graph",
