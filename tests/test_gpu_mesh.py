@@ -55,7 +55,7 @@ def test_mesh_exchange_between_processes(world, tmp_path):
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("form", ["mesh", "allreduce"])
-@pytest.mark.parametrize("cfg", [(41, 5, 16, 8), (501, 10, 500, 64)])
+@pytest.mark.parametrize("cfg", [(41, 5, 16, 8, "div"), (501, 10, 500, 64, "div"), (501, 10, 500, 64, "gp")])
 def test_late_gradient_dp_step_equals_the_fused_single_gpu_step(form, cfg, monkeypatch):
     """The data-parallel step in its "late gradients" shape (whole chain first, all weight gradients + column sums STORED by
     one launch -- wfd_gemm_f32_multi_grad --, then ONE exchange: the mesh launch that sums, applies RMSprop and
@@ -66,10 +66,10 @@ def test_late_gradient_dp_step_equals_the_fused_single_gpu_step(form, cfg, monke
     from wfd_gan_amd.engine import TrainEngine
     monkeypatch.setenv("WFD_DP_MESH", "1" if form == "mesh" else "0")
     monkeypatch.setenv("WFD_DP_LATE_GRADS", "1")
-    S, C, Z, B = cfg
-    st, e0, Xs, y = _setup(S, C, Z, B, "div")
+    S, C, Z, B, penalty = cfg
+    st, e0, Xs, y = _setup(S, C, Z, B, penalty)
     mk = lambda **kw: TrainEngine(S, C, Z, B, e0.scaler_min, e0.scaler_max, e0.generator_state(), e0.discriminator_state(),
-                                  {k: v for k, v in st.DF.items()}, device=DEV, **kw)
+                                  {k: v for k, v in st.DF.items()}, device=DEV, penalty=penalty, **kw)
     e1, e2 = mk(fuse_opt=True), mk(world_size=1, force_sync=True)
     assert e1.fuse_d and e1.fuse_g and e2.dp and e2.late_grads and e2.mesh_dp == (form == "mesh")
     for e in (e1, e2):
