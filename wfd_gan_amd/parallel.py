@@ -361,6 +361,9 @@ class MeshSync:
         dist.all_gather_object(allids, mine, group=self.group)
         if any(x is None for x in allids):
             return self.world             # the GPU cannot be identified: assume the worst
+        if len({x[0] for x in allids}) > 1:
+            raise ValueError("the mesh exchange maps the peers' memory through hipIpcMemHandle: all ranks must be on ONE "
+                             f"node, found {sorted({x[0] for x in allids})}")
         return sum(1 for x in allids if x == mine)
 
     def view(self, off: int, n: int) -> torch.Tensor:
