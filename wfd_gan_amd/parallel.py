@@ -310,6 +310,7 @@ class MeshSync:
         self._opened: List[int] = []
         n = int(region_floats)
         with torch.cuda.device(self.device):
+            sharing = self._ranks_on_my_gpu()          # (also refuses ranks on more than one node, before any mapping)
             hd, hf = ctypes.create_string_buffer(64), ctypes.create_string_buffer(64)
             pd, pf = ctypes.c_void_p(), ctypes.c_void_p()
             lib.mesh_alloc(4 * n, 0, ctypes.addressof(pd), ctypes.addressof(hd))
@@ -339,7 +340,6 @@ class MeshSync:
             self.base = torch.as_tensor(self.region, device=self.device)
             # every workgroup of an exchange waits for the peers, so all workgroups of all ranks on one GPU must be resident
             # together: ranks that share a GPU (test rigs) split the library's default of 128 workgroups
-            sharing = self._ranks_on_my_gpu()
             blocks = int(os.environ.get("WFD_MESH_BLOCKS", "0")) or 128 // sharing
             lib.mesh_set_max_blocks(self.mesh, max(1, min(256, blocks)))
             # bound of every in-kernel wait for a peer (a rank busy on the host -- rank 0 writing a checkpoint -- keeps the
