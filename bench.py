@@ -135,6 +135,75 @@ def live_traffic(timeout_s: float = 90.0):
         shutil.rmtree(tmp, ignore_errors=True)
 
 
+def large_batch_point(args, device, B: int = 4096):
+    """BASELINE configs[3] (large-batch sweep), one point: the same step at B rows, L = 1400, f32 operands -- whole-step
+    iterations/s and the contraction core's TFLOP/s (tools/sweep_batch.py's protocol: >= 0.3 s timed after >= 0.1 s warm-up;
+    parity of this shape: tests/test_gpu_step.py::test_large_batch_step_exact_on_own_parameters)."""
+    a2 = argparse.Namespace(**{**vars(args), "batch": B, "inst": max(200, 2 * B // 100 + 1), "penalty": "div"})
+    eng, _ = build_engine(a2, 0, 1, device)
+    eng.capture_graphs()
+    run_steps(eng, 0, 6)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    run_steps(eng, 6, 6)
+    torch.cuda.synchronize()
+    per = (time.perf_counter() - t0) / 6
+    warm = 3 * max(1, int(0.1 / per / 3))
+    steps = 3 * max(10, int(0.3 / per / 3))
+    run_steps(eng, 12, warm)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    run_steps(eng, 12 + warm, steps)
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    roof = gemm_roofline(eng, rep=4, rounds=2)
+    out = {"batch": B, "iterations_per_s": steps / dt, "samples_per_s": steps * B / dt, "core_tflops": roof["tflops"],
+           "frac_of_f32_mfma_peak": roof["tflops"] / PEAK_F32_MFMA_TFLOPS, "avg_us_per_launch": roof["avg_us"],
+           "note": "config 4 (large batch): the same step at 4096 rows per batch, L = 1400, f32 operands, single-iteration plans"}
+    del eng
+    torch.cuda.empty_cache()
+    return out
+
+
+def df_training_point(device, B: int = 128, L: int = 1400, C: int = 100, steps: int = 40):
+    """DF observer training (src/train_df.py:111-161: batch 128, Adamax, train-mode BatchNorm + dropout), steps/s
+    of the HIP-graph replay of wfd_gan_amd.df_engine.DFTrainEngine on synthetic bursts (tools/df_train_bench.py's protocol)."""
+    from wfd_gan_amd.df_engine import DFTrainEngine
+    from wfd_gan_amd.model import DF
+    torch.manual_seed(0)
+    eng = DFTrainEngine(L, C, B, DF(L, C).state_dict())
+    g = torch.Generator().manual_seed(1)
+    eng.set_batch(torch.rand(B, L, generator=g), torch.randint(0, C, (B,), generator=g))
+
+    def step():
+        eng.draw_masks()
+        eng.plan.run()
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        for _ in range(3):
+            step()
+    torch.cuda.current_stream().wait_stream(side)
+    torch.cuda.synchronize()
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph):
+        step()
+    for _ in range(5):
+        graph.replay()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        graph.replay()
+    torch.cuda.synchronize()
+    sps = steps / (time.perf_counter() - t0)
+    out = {"steps_per_s": sps, "samples_per_s": sps * B, "batch": B, "launches_per_step": len(eng.plan.calls),
+           "note": "DF observer training step (batch 128, L = 1400, 100 classes, fp32, Adamax), HIP-graph replay; parity: "
+                   "tests/test_gpu_df_train.py; CPU oracle on 16 threads: ~30 steps/s (tools/df_train_bench.py)"}
+    del graph, eng
+    torch.cuda.empty_cache()
+    return out
+
+
 def gemm_roofline(eng, plans=None, rep=16, rounds=3):
     """Live timing of the dominant kernel (the fp32 MFMA GEMM core, all its layouts) at the launches of one group of
     three iterations (3 D-steps + 1 G-step).  Every GEMM launch of the fast-mode plans is captured `rep` times
@@ -671,6 +740,8 @@ def main():
             torch.cuda.empty_cache()
         if args.operands == "f32" and args.batch == 64 and args.seq_len == 1401 and args.classes == 100 and args.inst == 1000:
             extras["cli_epoch"] = cli_epoch(device)
+            extras["large_batch"] = large_batch_point(args, device)
+            extras["df_training"] = df_training_point(device)
     if eng._mesh is not None:
         eng._mesh.check()                 # a timed-out wait for a peer would make the line meaningless: fail before printing it
     if rank == 0:
