@@ -54,6 +54,7 @@ def measure(reps=3):
     return best * 1e6, shapes
 
 
+measure(reps=1)                 # (the first engine of a process reads 3-4 % slow: clocks, allocator, lazy module loads)
 base, shapes = measure()
 uniq = []
 for s in shapes:
