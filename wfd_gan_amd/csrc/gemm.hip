@@ -453,6 +453,40 @@ __global__ __launch_bounds__(NTHREADS) void gemm_f32_rms_multi_kernel(MultiArgs 
 // MFMA sequence, same rmsprop_update), so the launch is bit-identical to the one-tile-per-workgroup form; which workgroup
 // computes a tile cannot matter.  Exit: a workgroup leaves when its list index passes the group's tile count (static lists,
 // no queue, no flag, no wait on another workgroup).
+// The square averages are touched by this launch only, once per step (45.6 MB read + written per critic step): as
+// NON-TEMPORAL accesses they stream past the caches instead of evicting what the next launches read.  Same-session A/B of
+// the whole step (round 3): everything cacheable 3493, everything streaming (-DWFD_RMS_NT=1) 3560, parameters' stores
+// cacheable (=2) 3570, ONLY the square averages streaming (=3, the default) 3586 it/s: +2.7 % -- the new parameters are
+// what the next step's products read, so they stay cacheable.  The launch itself takes the same time either way; the
+// gain is in the launches after it.
+#ifndef WFD_RMS_NT
+#define WFD_RMS_NT 3
+#endif
+#define WFD_NT_LOAD(p) __builtin_nontemporal_load(p)
+#define WFD_NT_STORE(v, p) __builtin_nontemporal_store(v, p)
+#define WFD_T_LOAD(p) (*(p))
+#define WFD_T_STORE(v, p) (*(p) = (v))
+#if WFD_RMS_NT == 1            // everything streams
+#define WFD_RMS_P_LOAD WFD_NT_LOAD
+#define WFD_RMS_P_STORE WFD_NT_STORE
+#define WFD_RMS_S_LOAD WFD_NT_LOAD
+#define WFD_RMS_S_STORE WFD_NT_STORE
+#elif WFD_RMS_NT == 2          // the new parameters stay cacheable (the next step's products read them)
+#define WFD_RMS_P_LOAD WFD_NT_LOAD
+#define WFD_RMS_P_STORE WFD_T_STORE
+#define WFD_RMS_S_LOAD WFD_NT_LOAD
+#define WFD_RMS_S_STORE WFD_NT_STORE
+#elif WFD_RMS_NT == 3          // only the square averages stream
+#define WFD_RMS_P_LOAD WFD_T_LOAD
+#define WFD_RMS_P_STORE WFD_T_STORE
+#define WFD_RMS_S_LOAD WFD_NT_LOAD
+#define WFD_RMS_S_STORE WFD_NT_STORE
+#else
+#define WFD_RMS_P_LOAD WFD_T_LOAD
+#define WFD_RMS_P_STORE WFD_T_STORE
+#define WFD_RMS_S_LOAD WFD_T_LOAD
+#define WFD_RMS_S_STORE WFD_T_STORE
+#endif
 struct PersistArgs {
     MultiArgs m;
     int small_blocks, nslots;
@@ -611,8 +645,8 @@ __global__ __launch_bounds__(NTHREADS, WPE) void gemm_f32_rms_persist_kernel(Per
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int prow = min(m0 + row0(j) + (r & 3) + 8 * (r >> 2) + 4 * h, pm.M - 1);
-                pp[j][r] = pm.P[(long)prow * pm.ldp + pcol];
-                sv[j][r] = pm.sq[(long)prow * pm.ldp + pcol];
+                pp[j][r] = WFD_RMS_P_LOAD(pm.P + (long)prow * pm.ldp + pcol);
+                sv[j][r] = WFD_RMS_S_LOAD(pm.sq + (long)prow * pm.ldp + pcol);
             }
     };
     for (;;) {
@@ -661,8 +695,8 @@ __global__ __launch_bounds__(NTHREADS, WPE) void gemm_f32_rms_persist_kernel(Per
                             pm.P[(long)row * pm.ldp + col] = acc[j][r];
                         } else {
                             rmsprop_update(pp[j][r], sv[j][r], acc[j][r], a.m.g[0].lr, a.m.g[0].alpha, a.m.g[0].eps);
-                            pm.sq[(long)row * pm.ldp + col] = sv[j][r];
-                            pm.P[(long)row * pm.ldp + col] = pp[j][r];
+                            WFD_RMS_S_STORE(sv[j][r], pm.sq + (long)row * pm.ldp + col);
+                            WFD_RMS_P_STORE(pp[j][r], pm.P + (long)row * pm.ldp + col);
                         }
                     }
                 }
