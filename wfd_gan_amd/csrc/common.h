@@ -60,6 +60,17 @@ __device__ __forceinline__ void rmsprop_update(float& p, float& s, float g, floa
 #endif
 }
 
+// 16-byte non-temporal accesses: data that is touched once per step (square averages, gradients on their way into the
+// optimizer, the sampler's final bursts) streams past the caches instead of evicting what the next launches read
+__device__ __forceinline__ float4 nt_load4(const float* p) {
+    const f32x4 v = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(p));
+    return make_float4(v[0], v[1], v[2], v[3]);
+}
+__device__ __forceinline__ void nt_store4(float* p, float4 v) {
+    const f32x4 t = {v.x, v.y, v.z, v.w};
+    __builtin_nontemporal_store(t, reinterpret_cast<f32x4*>(p));
+}
+
 static inline int cdiv(long a, long b) { return (int)((a + b - 1) / b); }
 
 __device__ __forceinline__ float wave_sum(float v) {

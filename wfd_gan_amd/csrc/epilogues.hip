@@ -355,14 +355,15 @@ __global__ void rmsprop_kernel(float* __restrict__ p, const float* __restrict__ 
     const long stride = (long)gridDim.x * blockDim.x * 4;
     for (long i = ((long)blockIdx.x * blockDim.x + threadIdx.x) * 4; i < n; i += stride) {
         if (i + 3 < n) {
-            float4 gv = *reinterpret_cast<const float4*>(g + i);
-            float4 sv = *reinterpret_cast<const float4*>(sq + i);
+            // gradients and square averages are touched once per step: they stream past the caches (as in the fused launch)
+            float4 gv = nt_load4(g + i);
+            float4 sv = nt_load4(sq + i);
             float4 pv = *reinterpret_cast<const float4*>(p + i);
             rmsprop_update(pv.x, sv.x, gv.x * gscale, lr, alpha, eps);
             rmsprop_update(pv.y, sv.y, gv.y * gscale, lr, alpha, eps);
             rmsprop_update(pv.z, sv.z, gv.z * gscale, lr, alpha, eps);
             rmsprop_update(pv.w, sv.w, gv.w * gscale, lr, alpha, eps);
-            *reinterpret_cast<float4*>(sq + i) = sv;
+            nt_store4(sq + i, sv);
             *reinterpret_cast<float4*>(p + i) = pv;
         } else {
             for (long j = i; j < n; ++j) {

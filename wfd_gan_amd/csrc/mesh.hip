@@ -104,7 +104,6 @@ __global__ __launch_bounds__(MESH_THREADS) void mesh_exchange_kernel(MeshDev m, 
         src[p] = reinterpret_cast<const float4*>(m.data[p] + goff);
         dst[p] = reinterpret_cast<float4*>(m.data[p] + (OPT ? o.poff : goff));
     }
-    float4* sq4 = reinterpret_cast<float4*>(o.sq);
     const long stride = (long)gridDim.x * MESH_THREADS;
     for (long i0 = a + (long)blockIdx.x * MESH_THREADS + tid; i0 < b; i0 += U * stride) {
         float4 v[U][W], pv[U], sv[U];
@@ -113,8 +112,12 @@ __global__ __launch_bounds__(MESH_THREADS) void mesh_exchange_kernel(MeshDev m, 
             const long i = i0 + u * stride;
             if (i < b) {
 #pragma unroll
-                for (int p = 0; p < W; ++p) v[u][p] = src[p][i];
-                if constexpr (OPT) { pv[u] = dst[r][i]; sv[u] = sq4[i]; }
+                for (int p = 0; p < W; ++p) {
+                    // (fused optimizer form: the gradients are read once -- they stream past the caches)
+                    if constexpr (OPT) v[u][p] = nt_load4(reinterpret_cast<const float*>(src[p] + i));
+                    else v[u][p] = src[p][i];
+                }
+                if constexpr (OPT) { pv[u] = dst[r][i]; sv[u] = nt_load4(o.sq + 4 * i); }
             }
         }
 #pragma unroll
@@ -129,7 +132,7 @@ __global__ __launch_bounds__(MESH_THREADS) void mesh_exchange_kernel(MeshDev m, 
                     rmsprop_update(pv[u].y, sv[u].y, acc.y * o.gscale, o.lr, o.alpha, o.eps);
                     rmsprop_update(pv[u].z, sv[u].z, acc.z * o.gscale, o.lr, o.alpha, o.eps);
                     rmsprop_update(pv[u].w, sv[u].w, acc.w * o.gscale, o.lr, o.alpha, o.eps);
-                    sq4[i] = sv[u];
+                    nt_store4(o.sq + 4 * i, sv[u]);               // touched once per step: streams past the caches
                     acc = pv[u];
                 }
 #pragma unroll

@@ -278,7 +278,7 @@ __global__ void sample_post_kernel(const float* __restrict__ Y, int ldy, int S, 
             v = (int)rintf(xs[lo + j]);
             if (v == 0) v = 1;
         }
-        out[(long)m * ldo + j] = v;
+        __builtin_nontemporal_store(v, out + (long)m * ldo + j);      // never read again on the device: streams past the caches
     }
     if (threadIdx.x == 0) len_out[m] = n;
 }
@@ -325,7 +325,7 @@ __global__ void sample_post_v4_kernel(const float* __restrict__ Y, int ldy, int 
             v = (int)rintf(xs[lo + j]);
             if (v == 0) v = 1;
         }
-        out[(long)m * ldo + j] = v;
+        __builtin_nontemporal_store(v, out + (long)m * ldo + j);      // never read again on the device: streams past the caches
     }
     if (threadIdx.x == 0) len_out[m] = n;
 }
@@ -382,7 +382,7 @@ __global__ void sample_post_mode_kernel(const float* __restrict__ Y, int ldy, in
                 if (mode != 3 && v == 0) v = 1;
             }
         }
-        out[(long)m * ldo + j] = v;
+        __builtin_nontemporal_store(v, out + (long)m * ldo + j);      // never read again on the device: streams past the caches
     }
     if (threadIdx.x == 0) len_out[m] = n;
 }
