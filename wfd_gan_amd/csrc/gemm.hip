@@ -210,6 +210,41 @@ __device__ __forceinline__ f32x4 read_frag(const float* __restrict__ S, int row0
 // EPI: 0 raw slabs; 1 fused store (epi_store); 2 RMSprop in the store with the parameter / square-average tile PREFETCHED
 // into registers right after the first k-tile, so that their 2 x 16 loads per lane land during the k-loop instead of
 // stalling the store (the store then only adds the second write stream).
+// The square averages are touched by the weight-gradient + RMSprop launches only, once per step (45.6 MB read + written per critic step): as
+// NON-TEMPORAL accesses they stream past the caches instead of evicting what the next launches read.  Same-session A/B of
+// the whole step (round 3): everything cacheable 3493, everything streaming (-DWFD_RMS_NT=1) 3560, parameters' stores
+// cacheable (=2) 3570, ONLY the square averages streaming (=3, the default) 3586 it/s: +2.7 % -- the new parameters are
+// what the next step's products read, so they stay cacheable.  The launch itself takes the same time either way; the
+// gain is in the launches after it.
+#ifndef WFD_RMS_NT
+#define WFD_RMS_NT 3
+#endif
+#define WFD_NT_LOAD(p) __builtin_nontemporal_load(p)
+#define WFD_NT_STORE(v, p) __builtin_nontemporal_store(v, p)
+#define WFD_T_LOAD(p) (*(p))
+#define WFD_T_STORE(v, p) (*(p) = (v))
+#if WFD_RMS_NT == 1            // everything streams
+#define WFD_RMS_P_LOAD WFD_NT_LOAD
+#define WFD_RMS_P_STORE WFD_NT_STORE
+#define WFD_RMS_S_LOAD WFD_NT_LOAD
+#define WFD_RMS_S_STORE WFD_NT_STORE
+#elif WFD_RMS_NT == 2          // the new parameters stay cacheable (the next step's products read them)
+#define WFD_RMS_P_LOAD WFD_NT_LOAD
+#define WFD_RMS_P_STORE WFD_T_STORE
+#define WFD_RMS_S_LOAD WFD_NT_LOAD
+#define WFD_RMS_S_STORE WFD_NT_STORE
+#elif WFD_RMS_NT == 3          // only the square averages stream
+#define WFD_RMS_P_LOAD WFD_T_LOAD
+#define WFD_RMS_P_STORE WFD_T_STORE
+#define WFD_RMS_S_LOAD WFD_NT_LOAD
+#define WFD_RMS_S_STORE WFD_NT_STORE
+#else
+#define WFD_RMS_P_LOAD WFD_T_LOAD
+#define WFD_RMS_P_STORE WFD_T_STORE
+#define WFD_RMS_S_LOAD WFD_T_LOAD
+#define WFD_RMS_S_STORE WFD_T_STORE
+#endif
+
 template <bool AKC, bool BKC, int VA, int VB, bool IM2COL, bool NARROW, int EPI>
 __device__ __forceinline__ void gemm_f32_body(const GemmArgs& g, float* __restrict__ lds, int bx, int by, int bz) {
     // lds: 4 * TILE_F floats; buffer c: A tile at lds + 2c*TILE_F, B tile right behind it
@@ -266,7 +301,7 @@ __device__ __forceinline__ void gemm_f32_body(const GemmArgs& g, float* __restri
         for (int r = 0; r < 16; ++r) {
             const int prow = min(m0 + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * h, g.M - 1);
             pp[r] = g.P[(long)prow * g.ldp + pcol];
-            sv[r] = g.sq[(long)prow * g.ldp + pcol];
+            sv[r] = WFD_RMS_S_LOAD(g.sq + (long)prow * g.ldp + pcol);
         }
     };
     int cur = 0;
@@ -333,7 +368,7 @@ __device__ __forceinline__ void gemm_f32_body(const GemmArgs& g, float* __restri
             if (row < g.M) {
                 if constexpr (EPI == 2) {
                     rmsprop_update(pp[r], sv[r], acc[r], g.lr, g.alpha, g.eps);
-                    g.sq[(long)row * g.ldp + col] = sv[r];
+                    WFD_RMS_S_STORE(sv[r], g.sq + (long)row * g.ldp + col);
                     P[(long)row * g.ldp + col] = pp[r];
                 } else if constexpr (EPI == 1) {
                     epi_store(g, P, acc[r], row, col);
@@ -453,40 +488,6 @@ __global__ __launch_bounds__(NTHREADS) void gemm_f32_rms_multi_kernel(MultiArgs 
 // MFMA sequence, same rmsprop_update), so the launch is bit-identical to the one-tile-per-workgroup form; which workgroup
 // computes a tile cannot matter.  Exit: a workgroup leaves when its list index passes the group's tile count (static lists,
 // no queue, no flag, no wait on another workgroup).
-// The square averages are touched by this launch only, once per step (45.6 MB read + written per critic step): as
-// NON-TEMPORAL accesses they stream past the caches instead of evicting what the next launches read.  Same-session A/B of
-// the whole step (round 3): everything cacheable 3493, everything streaming (-DWFD_RMS_NT=1) 3560, parameters' stores
-// cacheable (=2) 3570, ONLY the square averages streaming (=3, the default) 3586 it/s: +2.7 % -- the new parameters are
-// what the next step's products read, so they stay cacheable.  The launch itself takes the same time either way; the
-// gain is in the launches after it.
-#ifndef WFD_RMS_NT
-#define WFD_RMS_NT 3
-#endif
-#define WFD_NT_LOAD(p) __builtin_nontemporal_load(p)
-#define WFD_NT_STORE(v, p) __builtin_nontemporal_store(v, p)
-#define WFD_T_LOAD(p) (*(p))
-#define WFD_T_STORE(v, p) (*(p) = (v))
-#if WFD_RMS_NT == 1            // everything streams
-#define WFD_RMS_P_LOAD WFD_NT_LOAD
-#define WFD_RMS_P_STORE WFD_NT_STORE
-#define WFD_RMS_S_LOAD WFD_NT_LOAD
-#define WFD_RMS_S_STORE WFD_NT_STORE
-#elif WFD_RMS_NT == 2          // the new parameters stay cacheable (the next step's products read them)
-#define WFD_RMS_P_LOAD WFD_NT_LOAD
-#define WFD_RMS_P_STORE WFD_T_STORE
-#define WFD_RMS_S_LOAD WFD_NT_LOAD
-#define WFD_RMS_S_STORE WFD_NT_STORE
-#elif WFD_RMS_NT == 3          // only the square averages stream
-#define WFD_RMS_P_LOAD WFD_T_LOAD
-#define WFD_RMS_P_STORE WFD_T_STORE
-#define WFD_RMS_S_LOAD WFD_NT_LOAD
-#define WFD_RMS_S_STORE WFD_NT_STORE
-#else
-#define WFD_RMS_P_LOAD WFD_T_LOAD
-#define WFD_RMS_P_STORE WFD_T_STORE
-#define WFD_RMS_S_LOAD WFD_T_LOAD
-#define WFD_RMS_S_STORE WFD_T_STORE
-#endif
 struct PersistArgs {
     MultiArgs m;
     int small_blocks, nslots;
