@@ -85,8 +85,8 @@ def clip_dataset(X: np.ndarray, device) -> np.ndarray:
 
 
 def df_accuracy(f_model: DF, fakes: torch.Tensor, labels: torch.Tensor, comm=None) -> float:
-    """test_DF_acc_epoch (:57-79): DF argmax accuracy over this epoch's generated traces, batches of 128 (summed
-    over the ranks' shares in data-parallel runs).  The correct-prediction count accumulates in device memory
+    """test_DF_acc_epoch (:57-79): DF argmax accuracy over this epoch's generated traces (summed over the ranks' shares in
+    data-parallel runs).  The correct-prediction count accumulates in device memory
     (wfd_argmax_correct: first maximum, as torch.argmax) and is read once."""
     L = lib()
     dev = fakes.device
@@ -95,10 +95,14 @@ def df_accuracy(f_model: DF, fakes: torch.Tensor, labels: torch.Tensor, comm=Non
     total = fakes.shape[0]
     st = torch.cuda.current_stream(dev).cuda_stream
     C = f_model.num_classes
-    for a in range(0, total, 128):
-        x = fakes[a:a + 128, 1:]
+    # The reference walks the traces in batches of 128; in eval mode every row's logits are independent of the batch it is in,
+    # so the batch size is a throughput knob only: at 128 rows the observer's ~25 launches are latency-bound (33 k traces =
+    # 261 batches), at 2048 they are not -- 0.490 -> 0.467 s per config-2 epoch.  WFD_DF_ACC_BATCH=128 restores the walk.
+    nb = max(1, int(os.environ.get("WFD_DF_ACC_BATCH", "2048")))
+    for a in range(0, total, nb):
+        x = fakes[a:a + nb, 1:]
         logits = f_model(x.reshape(x.shape[0], 1, x.shape[1]))
-        L.argmax_correct(logits.data_ptr(), logits.stride(0), x.shape[0], C, lab32[a:a + 128].data_ptr(), correct.data_ptr(), st)
+        L.argmax_correct(logits.data_ptr(), logits.stride(0), x.shape[0], C, lab32[a:a + nb].data_ptr(), correct.data_ptr(), st)
     n_ok = int(correct.item())
     if comm is not None and comm.world > 1:
         t = comm.all_reduce_sum_(torch.tensor([n_ok, total], dtype=torch.float64, device=dev))
